@@ -1,0 +1,157 @@
+/*
+ * platgpu.h -- C ABI of libplatgpu.so: batched read-to-haplotype alignment and
+ * likelihood on an AMD MI355X (gfx950), the device replacement for the
+ * per-pair CPU path of Platypus 0.1.5.
+ *
+ * Conventions: every function returns PG_OK (0) or a negative PG_ERR_* code
+ * and never throws or longjmps across the boundary; every buffer is owned by
+ * the caller; a context belongs to one host thread at a time; all work of a
+ * context runs on one HIP stream created with the context.  There is no CPU
+ * fallback: without a usable gfx950 device pg_ctx_create fails.
+ *
+ * What each entry point replaces in the reference (paths relative to the
+ * reference checkout) is cited on the declaration.
+ */
+#ifndef PLATGPU_H
+#define PLATGPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PG_ABI_VERSION 1
+
+enum {
+    PG_OK = 0,
+    PG_ERR_NO_DEVICE = -1,     /* no HIP device / wrong architecture                    */
+    PG_ERR_INVALID = -2,       /* bad argument (NULL, negative size, index out of range) */
+    PG_ERR_HIP = -3,           /* a HIP runtime call failed (see pg_last_error_string)   */
+    PG_ERR_UNSUPPORTED = -4,   /* input outside the supported domain (see below)         */
+    PG_ERR_STATE = -5          /* call order: nothing uploaded / nothing launched        */
+};
+
+/* score value of a pair for which the reference's assertion at
+ * platypus/calign.pyx:61 fails (slice would run past the haplotype end on the
+ * no-indel path); the reference's cdef function then returns likelihood 0.0. */
+#define PG_SCORE_ASSERT_FAILED (-1)
+
+/* largest haplotype the 7-mer anchoring accepts, platypus/calign.pyx:14,112,132 */
+#define PG_MAX_HASHED_HAP_LEN 16383
+
+/* kernel ids for pg_kernel_time_ms */
+enum { PG_K_ANCHOR = 0, PG_K_ALIGN = 1, PG_K_GENOTYPE = 2, PG_K_COUNT = 3 };
+
+typedef struct pg_ctx pg_ctx;
+
+/* ABI version of the loaded library (compare with PG_ABI_VERSION). */
+int pg_abi_version(void);
+
+/*
+ * One context per process and GPU.  `max_read_len` bounds the read length the
+ * context accepts (device haplotypes are stored with that many trailing 'N's,
+ * the extension platypus/calign.pyx:73-75 makes per call); 0 selects 512.
+ * Replaces: nothing in the reference (it has no device); it is the state the
+ * Cython layer keeps for the lifetime of a worker process (platypus/runner.py:132).
+ */
+int pg_ctx_create(int device_ordinal, int max_read_len, pg_ctx **out);
+int pg_ctx_destroy(pg_ctx *ctx);
+
+/* Text of the last error of this context (or of creation when ctx is NULL). */
+const char *pg_last_error_string(const pg_ctx *ctx);
+
+/*
+ * Alignment parameters: the arguments platypus/chaplotype.pyx:264 passes down
+ * (gapextend 3, nucprior 2, the homopolymer gap-open string of
+ * platypus/chaplotype.pyx:37-40, usehomopolgapq = 1).  `table` holds
+ * `table_len` phred+33 characters, 1..255 of them.  Defaults are those values.
+ */
+int pg_set_params(pg_ctx *ctx, int gapextend, int nucprior, const char *table, int table_len);
+
+/*
+ * Haplotypes of a batch: `n` sequences concatenated in `seq`, sequence i is
+ * seq[offsets[i] .. offsets[i+1]).  start_pos = Haplotype.startPos,
+ * var_seq_len = Haplotype.varSeqLen (platypus/chaplotype.pxd:8-25,
+ * platypus/chaplotype.pyx:59-78).  Replaces the per-call arguments hapSeq,
+ * hapStart, varSeqLen, hapLen of alignNoTraceback (platypus/calign.pxd:5-17)
+ * and the per-call gap-open table build of platypus/c/align.c:70-96, which
+ * becomes a per-haplotype run-length array computed once on upload.
+ * A haplotype with var_seq_len != 0 must be 15..16383 long (outside that range
+ * the reference itself reads out of bounds or fails its own assertions).
+ */
+int pg_haps_upload(pg_ctx *ctx, int n, const char *seq, const int64_t *offsets,
+                   const int32_t *start_pos, const int32_t *var_seq_len);
+
+/*
+ * Reads of a batch, the five cAlignedRead fields the path uses
+ * (platypus/samtoolsWrapper.pxd:293-315: seq, qual, pos, rlen, mapq), packed:
+ * ASCII bases and RAW phred qualities (no +33), read i at [offsets[i],
+ * offsets[i+1]).  Qualities must be <= 127 and mapq in 0..255 (BAM's ranges),
+ * lengths 1..max_read_len.
+ */
+int pg_reads_upload(pg_ctx *ctx, int n, const char *seq, const char *qual,
+                    const int64_t *offsets, const int32_t *pos, const int32_t *mapq);
+
+/*
+ * The (haplotype, read) pairs to score, indices into the uploaded batches.
+ * Replaces the loop of Haplotype.alignReads (platypus/chaplotype.pyx:259-268)
+ * over one individual's reads, for as many haplotypes/individuals/windows as
+ * the caller batches together.
+ */
+int pg_pairs_upload(pg_ctx *ctx, int64_t n_pairs, const int32_t *hap_idx, const int32_t *read_idx);
+
+/* Dense block: every haplotype in [hap_lo,hap_hi) x every read in
+ * [read_lo,read_hi), haplotype-major (pair = (h-hap_lo)*(read_hi-read_lo) + (r-read_lo)). */
+int pg_pairs_block(pg_ctx *ctx, int hap_lo, int hap_hi, int read_lo, int read_hi);
+
+/*
+ * Enqueue the anchoring and alignment kernels for the uploaded pairs on the
+ * context's stream (asynchronous).  Per pair this computes what
+ * alignNoTraceback does (platypus/calign.pyx:36-78): anchor =
+ * indexOfReadIntoHap (hapPos-8 clamped at 0 on the no-indel path, the 7-mer
+ * vote of hash_sequence + map_read, platypus/calign.pyx:99-158, otherwise),
+ * score = fastAlignmentRoutine (platypus/c/align.c:18-235) on the slice at
+ * that anchor, likelihood = min(1, exp(mLTOT*score)*(1-pW)+pW).
+ */
+int pg_align_launch(pg_ctx *ctx);
+
+/* Block until everything enqueued on the context has finished. */
+int pg_sync(pg_ctx *ctx);
+
+/*
+ * Copy results of the last launch to the host (synchronises first).  Any of
+ * the three outputs may be NULL.  score: int32 per pair, 0..2048 or
+ * PG_SCORE_ASSERT_FAILED; anchor: the slice start; likelihood: double per
+ * pair, bit-identical to the reference's libm arithmetic (the two exp()
+ * factors are tabulated on the host with the C library).
+ */
+int pg_results_fetch(pg_ctx *ctx, int32_t *score, int32_t *anchor, double *likelihood);
+
+/* upload pairs + launch + sync + fetch in one call */
+int pg_align_pairs(pg_ctx *ctx, int64_t n_pairs, const int32_t *hap_idx, const int32_t *read_idx,
+                   int32_t *score, int32_t *anchor, double *likelihood);
+
+/*
+ * Device time in milliseconds of kernel group `which` in the last
+ * pg_align_launch / pg_genotype_loglik, measured with HIP events on the
+ * context's stream.  Synchronises.
+ */
+int pg_kernel_time_ms(pg_ctx *ctx, int which, float *ms);
+
+/*
+ * Genotype log-likelihoods from the likelihoods of the last launch, which
+ * stay on the device: out[g] = sum over r in [0,n_reads) of
+ * log(0.5*(L[pair_base1[g]+r] + L[pair_base2[g]+r])), summed in read order.
+ * Replaces DiploidGenotype.calculateDataLikelihood (platypus/cgenotype.pyx:48-63)
+ * for n_gen (genotype, individual) combinations; pair_base* are pair indices of
+ * the first read of the two haplotypes' likelihood rows.  Relative error vs the
+ * reference's libm log <= 1e-9.
+ */
+int pg_genotype_loglik(pg_ctx *ctx, int64_t n_gen, const int64_t *pair_base1,
+                       const int64_t *pair_base2, const int32_t *n_reads, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLATGPU_H */

@@ -1,0 +1,522 @@
+// libplatgpu.so -- host side of the C ABI declared in include/platgpu.h.
+// One context = one device, one stream, grow-only device buffers.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "../../include/platgpu.h"
+#include "pg_kernels.hip.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;   // elements
+    hipError_t reserve(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
+        size_t want = n + n / 4 + 64;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), want * sizeof(T));
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+}  // namespace
+
+struct pg_ctx {
+    int device = 0;
+    int max_read_len = 512;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[2 * PG_K_COUNT] = {};
+    bool ev_valid[PG_K_COUNT] = {};
+    std::string err;
+
+    // parameters (platypus/chaplotype.pyx:264)
+    int gapextend = 3, nucprior = 2;
+    std::string table;
+    DevBuf<int16_t> d_tab4;
+    DevBuf<double> d_exp_score, d_exp_mapq;
+
+    // haplotypes
+    int n_haps = 0;
+    int max_hap_len = 0;
+    std::vector<int64_t> h_hap_off;      // host offsets (lengths)
+    std::vector<int32_t> h_hap_varlen;
+    DevBuf<uint8_t> d_hap_raw, d_hap, d_run;
+    DevBuf<int64_t> d_hap_soff, d_hap_doff;
+    DevBuf<int32_t> d_hap_len, d_hap_start, d_hap_varlen;
+
+    // reads
+    int n_reads = 0;
+    int max_rlen = 0;
+    bool uniform_rlen = true;
+    std::vector<int64_t> h_read_off;
+    DevBuf<uint8_t> d_rseq, d_rqual;
+    DevBuf<int64_t> d_roff;
+    DevBuf<int32_t> d_read_pos, d_read_mapq;
+
+    // pairs
+    int64_t n_pairs = 0;
+    int n_waves = 0;
+    int n_vote_haps = 0;
+    bool have_order = false;
+    DevBuf<int32_t> d_pair_hap, d_pair_read, d_order, d_vh_list, d_vh_pairs, d_anchor_in;
+    DevBuf<int64_t> d_vh_ptr;
+    DevBuf<pg::WaveDesc> d_waves;
+
+    // results
+    bool launched = false;
+    DevBuf<int32_t> d_score, d_anchor;
+    DevBuf<double> d_like;
+
+    // genotype scratch
+    DevBuf<int64_t> d_g1, d_g2;
+    DevBuf<int32_t> d_gn;
+    DevBuf<double> d_gout;
+};
+
+namespace {
+
+int fail(pg_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define PG_HIP(c, call)                                                                   \
+    do {                                                                                  \
+        hipError_t e_ = (call);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            return fail((c), PG_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+const char kDefaultTable[] = "NKJHFA=854210/.-,,+**))((('''&&&%%%$$$$#####\"\"\"\"\"";  // chaplotype.pyx:37-40
+
+int upload_params(pg_ctx* c) {
+    int16_t tab4[256];
+    const int n = (int)c->table.size();
+    for (int i = 0; i < 256; ++i) {
+        const int ch = (unsigned char)c->table[std::min(i, n - 1)];
+        tab4[i] = (int16_t)(4 * (ch - '!'));      // align.c:85
+    }
+    PG_HIP(c, c->d_tab4.reserve(256));
+    PG_HIP(c, hipMemcpyAsync(c->d_tab4.p, tab4, sizeof tab4, hipMemcpyHostToDevice, c->stream));
+    // likelihood factors with the host C library, so the device result is the
+    // same double the reference computes (calign.pyx:17,55,63)
+    const double mLTOT = -0.23025850929940459;
+    std::vector<double> es(2049), em(256);
+    for (int s = 0; s <= 2048; ++s) es[s] = std::exp(mLTOT * s);
+    for (int q = 0; q < 256; ++q) em[q] = std::exp(mLTOT * q);
+    PG_HIP(c, c->d_exp_score.reserve(es.size()));
+    PG_HIP(c, c->d_exp_mapq.reserve(em.size()));
+    PG_HIP(c, hipMemcpyAsync(c->d_exp_score.p, es.data(), es.size() * 8, hipMemcpyHostToDevice, c->stream));
+    PG_HIP(c, hipMemcpyAsync(c->d_exp_mapq.p, em.data(), em.size() * 8, hipMemcpyHostToDevice, c->stream));
+    PG_HIP(c, hipStreamSynchronize(c->stream));
+    return PG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pg_abi_version(void) { return PG_ABI_VERSION; }
+
+const char* pg_last_error_string(const pg_ctx* ctx) {
+    return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+int pg_ctx_create(int device_ordinal, int max_read_len, pg_ctx** out) {
+    if (!out) return fail(nullptr, PG_ERR_INVALID, "pg_ctx_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, PG_ERR_NO_DEVICE, "no HIP device visible");
+    if (device_ordinal < 0 || device_ordinal >= ndev)
+        return fail(nullptr, PG_ERR_INVALID, "device ordinal %d out of range (%d devices)", device_ordinal, ndev);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_ordinal) != hipSuccess)
+        return fail(nullptr, PG_ERR_HIP, "hipGetDeviceProperties failed");
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, PG_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only",
+                    device_ordinal, prop.gcnArchName);
+    if (max_read_len == 0) max_read_len = 512;
+    if (max_read_len < 1 || max_read_len > 16384)
+        return fail(nullptr, PG_ERR_INVALID, "max_read_len %d outside 1..16384", max_read_len);
+    pg_ctx* c = new pg_ctx;
+    c->device = device_ordinal;
+    c->max_read_len = max_read_len;
+    c->table = kDefaultTable;
+    if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
+        delete c;
+        return fail(nullptr, PG_ERR_HIP, "cannot create a stream on device %d", device_ordinal);
+    }
+    for (auto& e : c->ev)
+        if (hipEventCreate(&e) != hipSuccess) { delete c; return fail(nullptr, PG_ERR_HIP, "hipEventCreate failed"); }
+    int rc = upload_params(c);
+    if (rc != PG_OK) { g_create_error = c->err; delete c; return rc; }
+    *out = c;
+    return PG_OK;
+}
+
+int pg_ctx_destroy(pg_ctx* c) {
+    if (!c) return PG_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    c->d_tab4.release(); c->d_exp_score.release(); c->d_exp_mapq.release();
+    c->d_hap_raw.release(); c->d_hap.release(); c->d_run.release();
+    c->d_hap_soff.release(); c->d_hap_doff.release();
+    c->d_hap_len.release(); c->d_hap_start.release(); c->d_hap_varlen.release();
+    c->d_rseq.release(); c->d_rqual.release(); c->d_roff.release();
+    c->d_read_pos.release(); c->d_read_mapq.release();
+    c->d_pair_hap.release(); c->d_pair_read.release(); c->d_order.release();
+    c->d_vh_list.release(); c->d_vh_pairs.release(); c->d_anchor_in.release(); c->d_vh_ptr.release();
+    c->d_waves.release(); c->d_score.release(); c->d_anchor.release(); c->d_like.release();
+    c->d_g1.release(); c->d_g2.release(); c->d_gn.release(); c->d_gout.release();
+    for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return PG_OK;
+}
+
+int pg_set_params(pg_ctx* c, int gapextend, int nucprior, const char* table, int table_len) {
+    if (!c) return PG_ERR_INVALID;
+    if (!table || table_len < 1 || table_len > 255)
+        return fail(c, PG_ERR_INVALID, "gap-open table must hold 1..255 characters");
+    if (gapextend < 0 || gapextend > 255 || nucprior < 0 || nucprior > 255)
+        return fail(c, PG_ERR_INVALID, "gapextend/nucprior outside 0..255");
+    for (int i = 0; i < table_len; ++i)
+        if ((unsigned char)table[i] < '!' || (unsigned char)table[i] > '~')
+            return fail(c, PG_ERR_INVALID, "gap-open table character %d is not phred+33", i);
+    PG_HIP(c, hipSetDevice(c->device));
+    c->gapextend = gapextend;
+    c->nucprior = nucprior;
+    c->table.assign(table, table + table_len);
+    c->n_haps = 0;           // run-length cap depends on the table: haplotypes must be uploaded again
+    c->n_pairs = 0;
+    c->launched = false;
+    return upload_params(c);
+}
+
+int pg_haps_upload(pg_ctx* c, int n, const char* seq, const int64_t* off,
+                   const int32_t* start_pos, const int32_t* var_seq_len) {
+    if (!c) return PG_ERR_INVALID;
+    if (n < 0 || (n > 0 && (!seq || !off || !start_pos || !var_seq_len)))
+        return fail(c, PG_ERR_INVALID, "pg_haps_upload: bad arguments");
+    PG_HIP(c, hipSetDevice(c->device));
+    c->n_haps = 0; c->n_pairs = 0; c->launched = false;
+    if (n == 0) return PG_OK;
+    const int pad = c->max_read_len + 32;
+    std::vector<int64_t> doff(n + 1);
+    std::vector<int32_t> len(n);
+    int maxlen = 0;
+    for (int i = 0; i < n; ++i) {
+        const int64_t l = off[i + 1] - off[i];
+        if (l < 0 || l > (1 << 30)) return fail(c, PG_ERR_INVALID, "haplotype %d has length %lld", i, (long long)l);
+        if (var_seq_len[i] != 0 && l > PG_MAX_HASHED_HAP_LEN)
+            return fail(c, PG_ERR_UNSUPPORTED, "haplotype %d with indels is %lld long; the 7-mer anchoring takes < 16384", i, (long long)l);
+        // a shorter one makes the reference read past the 'N' extension it appends (calign.pyx:73-77)
+        if (var_seq_len[i] != 0 && l < 15)
+            return fail(c, PG_ERR_UNSUPPORTED, "haplotype %d with indels is only %lld long; at least 15 bases are needed", i, (long long)l);
+        len[i] = (int32_t)l;
+        maxlen = std::max(maxlen, (int)l);
+        doff[i] = (off[i] - off[0]) + (int64_t)i * pad;
+    }
+    const int64_t total = off[n] - off[0];
+    doff[n] = total + (int64_t)n * pad;
+    PG_HIP(c, c->d_hap_raw.reserve((size_t)total + 16));
+    PG_HIP(c, c->d_hap.reserve((size_t)doff[n] + 64));
+    PG_HIP(c, c->d_run.reserve((size_t)doff[n] + 64));
+    PG_HIP(c, c->d_hap_soff.reserve(n + 1));
+    PG_HIP(c, c->d_hap_doff.reserve(n + 1));
+    PG_HIP(c, c->d_hap_len.reserve(n));
+    PG_HIP(c, c->d_hap_start.reserve(n));
+    PG_HIP(c, c->d_hap_varlen.reserve(n));
+    std::vector<int64_t> soff(n + 1);
+    for (int i = 0; i <= n; ++i) soff[i] = off[i] - off[0];
+    PG_HIP(c, hipMemcpyAsync(c->d_hap_raw.p, seq + off[0], (size_t)total, hipMemcpyHostToDevice, c->stream));
+    PG_HIP(c, hipMemcpyAsync(c->d_hap_soff.p, soff.data(), (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    PG_HIP(c, hipMemcpyAsync(c->d_hap_doff.p, doff.data(), (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    PG_HIP(c, hipMemcpyAsync(c->d_hap_len.p, len.data(), n * 4, hipMemcpyHostToDevice, c->stream));
+    PG_HIP(c, hipMemcpyAsync(c->d_hap_start.p, start_pos, n * 4, hipMemcpyHostToDevice, c->stream));
+    PG_HIP(c, hipMemcpyAsync(c->d_hap_varlen.p, var_seq_len, n * 4, hipMemcpyHostToDevice, c->stream));
+    const int cap = (int)c->table.size() - 1;
+    const int grid = std::min(n, 65536);
+    hipLaunchKernelGGL(pg::k_pack_haps, dim3(grid), dim3(256), 0, c->stream, c->d_hap_raw.p, c->d_hap_soff.p,
+                       c->d_hap_doff.p, c->d_hap.p, c->d_run.p, n, pad, cap);
+    PG_HIP(c, hipGetLastError());
+    PG_HIP(c, hipStreamSynchronize(c->stream));   // host vectors above go out of scope
+    c->h_hap_off.assign(soff.begin(), soff.end());
+    c->h_hap_varlen.assign(var_seq_len, var_seq_len + n);
+    c->max_hap_len = maxlen;
+    c->n_haps = n;
+    return PG_OK;
+}
+
+int pg_reads_upload(pg_ctx* c, int n, const char* seq, const char* qual, const int64_t* off,
+                    const int32_t* pos, const int32_t* mapq) {
+    if (!c) return PG_ERR_INVALID;
+    if (n < 0 || (n > 0 && (!seq || !qual || !off || !pos || !mapq)))
+        return fail(c, PG_ERR_INVALID, "pg_reads_upload: bad arguments");
+    PG_HIP(c, hipSetDevice(c->device));
+    c->n_reads = 0; c->n_pairs = 0; c->launched = false;
+    if (n == 0) return PG_OK;
+    int maxl = 0, minl = 1 << 30;
+    for (int i = 0; i < n; ++i) {
+        const int64_t l = off[i + 1] - off[i];
+        if (l < 1 || l > c->max_read_len)
+            return fail(c, PG_ERR_UNSUPPORTED, "read %d has length %lld; this context takes 1..%d", i, (long long)l, c->max_read_len);
+        if (mapq[i] < 0 || mapq[i] > 255)
+            return fail(c, PG_ERR_UNSUPPORTED, "read %d has mapping quality %d outside 0..255", i, mapq[i]);
+        maxl = std::max(maxl, (int)l);
+        minl = std::min(minl, (int)l);
+    }
+    const int64_t total = off[n] - off[0];
+    {   // qualities are raw phred bytes; the reference reads them as signed char
+        const unsigned char* q = reinterpret_cast<const unsigned char*>(qual) + off[0];
+        unsigned char acc = 0;
+        for (int64_t i = 0; i < total; ++i) acc |= q[i];
+        if (acc & 0x80) return fail(c, PG_ERR_UNSUPPORTED, "a base quality above 127 was found");
+    }
+    PG_HIP(c, c->d_rseq.reserve((size_t)total + 64));
+    PG_HIP(c, c->d_rqual.reserve((size_t)total + 64));
+    PG_HIP(c, c->d_roff.reserve(n + 1));
+    PG_HIP(c, c->d_read_pos.reserve(n));
+    PG_HIP(c, c->d_read_mapq.reserve(n));
+    std::vector<int64_t> roff(n + 1);
+    for (int i = 0; i <= n; ++i) roff[i] = off[i] - off[0];
+    PG_HIP(c, hipMemcpyAsync(c->d_rseq.p, seq + off[0], (size_t)total, hipMemcpyHostToDevice, c->stream));
+    PG_HIP(c, hipMemcpyAsync(c->d_rqual.p, qual + off[0], (size_t)total, hipMemcpyHostToDevice, c->stream));
+    PG_HIP(c, hipMemcpyAsync(c->d_roff.p, roff.data(), (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    PG_HIP(c, hipMemcpyAsync(c->d_read_pos.p, pos, n * 4, hipMemcpyHostToDevice, c->stream));
+    PG_HIP(c, hipMemcpyAsync(c->d_read_mapq.p, mapq, n * 4, hipMemcpyHostToDevice, c->stream));
+    PG_HIP(c, hipStreamSynchronize(c->stream));
+    c->h_read_off.swap(roff);
+    c->max_rlen = maxl;
+    c->uniform_rlen = (maxl == minl);
+    c->n_reads = n;
+    return PG_OK;
+}
+
+int pg_pairs_upload(pg_ctx* c, int64_t np, const int32_t* hap_idx, const int32_t* read_idx) {
+    if (!c) return PG_ERR_INVALID;
+    if (np < 0 || np > 0x7fffffffLL || (np > 0 && (!hap_idx || !read_idx)))
+        return fail(c, PG_ERR_INVALID, "pg_pairs_upload: bad arguments");
+    if (c->n_haps == 0 || c->n_reads == 0)
+        return fail(c, PG_ERR_STATE, "upload haplotypes and reads before pairs");
+    PG_HIP(c, hipSetDevice(c->device));
+    c->n_pairs = 0; c->launched = false;
+    if (np == 0) return PG_OK;
+    for (int64_t p = 0; p < np; ++p)
+        if ((uint32_t)hap_idx[p] >= (uint32_t)c->n_haps || (uint32_t)read_idx[p] >= (uint32_t)c->n_reads)
+            return fail(c, PG_ERR_INVALID, "pair %lld refers to haplotype %d / read %d outside the uploaded batches",
+                        (long long)p, hap_idx[p], read_idx[p]);
+
+    // ---- wavefronts of equal read length ------------------------------------
+    std::vector<pg::WaveDesc> waves;
+    std::vector<int32_t> order;
+    c->have_order = !c->uniform_rlen;
+    if (c->uniform_rlen) {
+        const int len = c->max_rlen;
+        waves.reserve((size_t)(np + 63) / 64);
+        for (int64_t s = 0; s < np; s += 64)
+            waves.push_back({(int32_t)s, (int32_t)std::min<int64_t>(64, np - s), len, 0});
+    } else {
+        // counting sort by read length, stable: neighbours stay neighbours
+        std::vector<int64_t> cnt(c->max_rlen + 2, 0);
+        for (int64_t p = 0; p < np; ++p) cnt[(c->h_read_off[read_idx[p] + 1] - c->h_read_off[read_idx[p]]) + 1]++;
+        for (size_t l = 1; l < cnt.size(); ++l) cnt[l] += cnt[l - 1];
+        order.resize(np);
+        std::vector<int64_t> cur(cnt.begin(), cnt.end() - 1);
+        for (int64_t p = 0; p < np; ++p) {
+            const int l = (int)(c->h_read_off[read_idx[p] + 1] - c->h_read_off[read_idx[p]]);
+            order[cur[l]++] = (int32_t)p;
+        }
+        for (int l = 1; l <= c->max_rlen; ++l)
+            for (int64_t s = cnt[l]; s < cnt[l + 1]; s += 64)
+                waves.push_back({(int32_t)s, (int32_t)std::min<int64_t>(64, cnt[l + 1] - s), l, 0});
+    }
+
+    // ---- pairs on indel-bearing haplotypes, grouped by haplotype ---------------
+    std::vector<int32_t> vh_list, vh_pairs;
+    std::vector<int64_t> vh_ptr;
+    {
+        std::vector<int64_t> per_hap(c->n_haps + 1, 0);
+        int64_t nv = 0;
+        for (int64_t p = 0; p < np; ++p)
+            if (c->h_hap_varlen[hap_idx[p]] != 0) { per_hap[hap_idx[p] + 1]++; ++nv; }
+        if (nv > 0) {
+            std::vector<int64_t> start(c->n_haps + 1, 0);
+            for (int h = 0; h < c->n_haps; ++h) start[h + 1] = start[h] + per_hap[h + 1];
+            vh_pairs.resize(nv);
+            std::vector<int64_t> cur(start.begin(), start.end() - 1);
+            for (int64_t p = 0; p < np; ++p)
+                if (c->h_hap_varlen[hap_idx[p]] != 0) vh_pairs[cur[hap_idx[p]]++] = (int32_t)p;
+            for (int h = 0; h < c->n_haps; ++h)
+                if (start[h + 1] > start[h]) { vh_list.push_back(h); vh_ptr.push_back(start[h]); }
+            vh_ptr.push_back(nv);
+        }
+    }
+    c->n_vote_haps = (int)vh_list.size();
+
+    PG_HIP(c, c->d_pair_hap.reserve(np));
+    PG_HIP(c, c->d_pair_read.reserve(np));
+    PG_HIP(c, c->d_waves.reserve(waves.size()));
+    PG_HIP(c, c->d_score.reserve(np));
+    PG_HIP(c, c->d_anchor.reserve(np));
+    PG_HIP(c, c->d_anchor_in.reserve(np));
+    PG_HIP(c, c->d_like.reserve(np));
+    PG_HIP(c, hipMemcpyAsync(c->d_pair_hap.p, hap_idx, np * 4, hipMemcpyHostToDevice, c->stream));
+    PG_HIP(c, hipMemcpyAsync(c->d_pair_read.p, read_idx, np * 4, hipMemcpyHostToDevice, c->stream));
+    PG_HIP(c, hipMemcpyAsync(c->d_waves.p, waves.data(), waves.size() * sizeof(pg::WaveDesc), hipMemcpyHostToDevice, c->stream));
+    if (c->have_order) {
+        PG_HIP(c, c->d_order.reserve(np));
+        PG_HIP(c, hipMemcpyAsync(c->d_order.p, order.data(), np * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    if (c->n_vote_haps > 0) {
+        PG_HIP(c, c->d_vh_list.reserve(vh_list.size()));
+        PG_HIP(c, c->d_vh_ptr.reserve(vh_ptr.size()));
+        PG_HIP(c, c->d_vh_pairs.reserve(vh_pairs.size()));
+        PG_HIP(c, hipMemcpyAsync(c->d_vh_list.p, vh_list.data(), vh_list.size() * 4, hipMemcpyHostToDevice, c->stream));
+        PG_HIP(c, hipMemcpyAsync(c->d_vh_ptr.p, vh_ptr.data(), vh_ptr.size() * 8, hipMemcpyHostToDevice, c->stream));
+        PG_HIP(c, hipMemcpyAsync(c->d_vh_pairs.p, vh_pairs.data(), vh_pairs.size() * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    PG_HIP(c, hipStreamSynchronize(c->stream));
+    c->n_waves = (int)waves.size();
+    c->n_pairs = np;
+    return PG_OK;
+}
+
+int pg_pairs_block(pg_ctx* c, int hap_lo, int hap_hi, int read_lo, int read_hi) {
+    if (!c) return PG_ERR_INVALID;
+    if (hap_lo < 0 || hap_hi < hap_lo || hap_hi > c->n_haps || read_lo < 0 || read_hi < read_lo || read_hi > c->n_reads)
+        return fail(c, PG_ERR_INVALID, "pg_pairs_block: range outside the uploaded batches");
+    const int64_t nh = hap_hi - hap_lo, nr = read_hi - read_lo;
+    std::vector<int32_t> hi((size_t)(nh * nr)), ri((size_t)(nh * nr));
+    for (int64_t h = 0; h < nh; ++h)
+        for (int64_t r = 0; r < nr; ++r) { hi[h * nr + r] = (int32_t)(hap_lo + h); ri[h * nr + r] = (int32_t)(read_lo + r); }
+    return pg_pairs_upload(c, nh * nr, hi.data(), ri.data());
+}
+
+int pg_align_launch(pg_ctx* c) {
+    if (!c) return PG_ERR_INVALID;
+    if (c->n_pairs == 0) return fail(c, PG_ERR_STATE, "no pairs uploaded");
+    PG_HIP(c, hipSetDevice(c->device));
+    // anchoring of pairs on indel-bearing haplotypes
+    PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_ANCHOR], c->stream));
+    if (c->n_vote_haps > 0) {
+        int cnt_stride = c->max_hap_len + c->max_rlen + 8;
+        cnt_stride += cnt_stride & 1;
+        const size_t lds = (size_t)pg::kHashSize * 2 + (size_t)4 * cnt_stride * 2;
+        if (lds > 160 * 1024)
+            return fail(c, PG_ERR_UNSUPPORTED, "vote counters for haplotype length %d need %zu bytes of LDS", c->max_hap_len, lds);
+        PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_vote), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(pg::k_vote, dim3(c->n_vote_haps), dim3(256), lds, c->stream, c->d_hap.p, c->d_hap_doff.p,
+                           c->d_hap_len.p, c->d_rseq.p, c->d_roff.p, c->d_vh_list.p, c->d_vh_ptr.p, c->d_vh_pairs.p,
+                           c->d_pair_read.p, c->d_anchor_in.p, cnt_stride);
+        PG_HIP(c, hipGetLastError());
+    }
+    PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_ANCHOR + 1], c->stream));
+    c->ev_valid[PG_K_ANCHOR] = true;
+
+    pg::AlignArgs A;
+    A.hap = c->d_hap.p; A.run = c->d_run.p; A.hap_doff = c->d_hap_doff.p; A.hap_len = c->d_hap_len.p;
+    A.hap_start = c->d_hap_start.p; A.hap_varlen = c->d_hap_varlen.p;
+    A.rseq = c->d_rseq.p; A.rqual = c->d_rqual.p; A.roff = c->d_roff.p;
+    A.read_pos = c->d_read_pos.p; A.read_mapq = c->d_read_mapq.p;
+    A.pair_hap = c->d_pair_hap.p; A.pair_read = c->d_pair_read.p;
+    A.order = c->have_order ? c->d_order.p : nullptr;
+    A.waves = c->d_waves.p; A.anchor_in = c->d_anchor_in.p; A.tab4 = c->d_tab4.p;
+    A.exp_score = c->d_exp_score.p; A.exp_mapq = c->d_exp_mapq.p;
+    A.score = c->d_score.p; A.anchor = c->d_anchor.p; A.like = c->d_like.p;
+    A.n_waves = c->n_waves; A.ge4 = 4 * c->gapextend; A.np4 = 4 * c->nucprior;
+    PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_ALIGN], c->stream));
+    hipLaunchKernelGGL(pg::k_align, dim3((c->n_waves + 3) / 4), dim3(256), 0, c->stream, A);
+    PG_HIP(c, hipGetLastError());
+    PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_ALIGN + 1], c->stream));
+    c->ev_valid[PG_K_ALIGN] = true;
+    c->launched = true;
+    return PG_OK;
+}
+
+int pg_sync(pg_ctx* c) {
+    if (!c) return PG_ERR_INVALID;
+    PG_HIP(c, hipSetDevice(c->device));
+    PG_HIP(c, hipStreamSynchronize(c->stream));
+    return PG_OK;
+}
+
+int pg_results_fetch(pg_ctx* c, int32_t* score, int32_t* anchor, double* like) {
+    if (!c) return PG_ERR_INVALID;
+    if (!c->launched) return fail(c, PG_ERR_STATE, "nothing launched");
+    PG_HIP(c, hipSetDevice(c->device));
+    const size_t n = (size_t)c->n_pairs;
+    if (score) PG_HIP(c, hipMemcpyAsync(score, c->d_score.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (anchor) PG_HIP(c, hipMemcpyAsync(anchor, c->d_anchor.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (like) PG_HIP(c, hipMemcpyAsync(like, c->d_like.p, n * 8, hipMemcpyDeviceToHost, c->stream));
+    PG_HIP(c, hipStreamSynchronize(c->stream));
+    return PG_OK;
+}
+
+int pg_align_pairs(pg_ctx* c, int64_t np, const int32_t* hap_idx, const int32_t* read_idx,
+                   int32_t* score, int32_t* anchor, double* like) {
+    int rc = pg_pairs_upload(c, np, hap_idx, read_idx);
+    if (rc != PG_OK) return rc;
+    if (np == 0) return PG_OK;
+    rc = pg_align_launch(c);
+    if (rc != PG_OK) return rc;
+    return pg_results_fetch(c, score, anchor, like);
+}
+
+int pg_kernel_time_ms(pg_ctx* c, int which, float* ms) {
+    if (!c || !ms || which < 0 || which >= PG_K_COUNT) return PG_ERR_INVALID;
+    if (!c->ev_valid[which]) return fail(c, PG_ERR_STATE, "kernel group %d has not run", which);
+    PG_HIP(c, hipSetDevice(c->device));
+    PG_HIP(c, hipEventSynchronize(c->ev[2 * which + 1]));
+    PG_HIP(c, hipEventElapsedTime(ms, c->ev[2 * which], c->ev[2 * which + 1]));
+    return PG_OK;
+}
+
+int pg_genotype_loglik(pg_ctx* c, int64_t ng, const int64_t* b1, const int64_t* b2,
+                       const int32_t* nreads, double* out) {
+    if (!c) return PG_ERR_INVALID;
+    if (ng < 0 || (ng > 0 && (!b1 || !b2 || !nreads || !out)))
+        return fail(c, PG_ERR_INVALID, "pg_genotype_loglik: bad arguments");
+    if (!c->launched) return fail(c, PG_ERR_STATE, "no likelihoods on the device: launch an alignment first");
+    if (ng == 0) return PG_OK;
+    for (int64_t g = 0; g < ng; ++g)
+        if (nreads[g] < 0 || b1[g] < 0 || b2[g] < 0 || b1[g] + nreads[g] > c->n_pairs || b2[g] + nreads[g] > c->n_pairs)
+            return fail(c, PG_ERR_INVALID, "genotype row %lld reaches outside the pair list", (long long)g);
+    PG_HIP(c, hipSetDevice(c->device));
+    PG_HIP(c, c->d_g1.reserve(ng)); PG_HIP(c, c->d_g2.reserve(ng));
+    PG_HIP(c, c->d_gn.reserve(ng)); PG_HIP(c, c->d_gout.reserve(ng));
+    PG_HIP(c, hipMemcpyAsync(c->d_g1.p, b1, ng * 8, hipMemcpyHostToDevice, c->stream));
+    PG_HIP(c, hipMemcpyAsync(c->d_g2.p, b2, ng * 8, hipMemcpyHostToDevice, c->stream));
+    PG_HIP(c, hipMemcpyAsync(c->d_gn.p, nreads, ng * 4, hipMemcpyHostToDevice, c->stream));
+    PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_GENOTYPE], c->stream));
+    hipLaunchKernelGGL(pg::k_genotype, dim3((unsigned)((ng * 64 + 255) / 256)), dim3(256), 0, c->stream,
+                       c->d_like.p, c->d_g1.p, c->d_g2.p, c->d_gn.p, c->d_gout.p, ng);
+    PG_HIP(c, hipGetLastError());
+    PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_GENOTYPE + 1], c->stream));
+    c->ev_valid[PG_K_GENOTYPE] = true;
+    PG_HIP(c, hipMemcpyAsync(out, c->d_gout.p, ng * 8, hipMemcpyDeviceToHost, c->stream));
+    PG_HIP(c, hipStreamSynchronize(c->stream));
+    return PG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,158 @@
+"""ctypes binding of libplatgpu.so (include/platgpu.h).
+
+The library is the product: if it is missing or does not load, importing this
+module raises -- there is no Python or CPU fallback for the alignment path.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libplatgpu.so")
+
+PG_OK = 0
+PG_ERR_NO_DEVICE, PG_ERR_INVALID, PG_ERR_HIP, PG_ERR_UNSUPPORTED, PG_ERR_STATE = -1, -2, -3, -4, -5
+PG_SCORE_ASSERT_FAILED = -1
+PG_K_ANCHOR, PG_K_ALIGN, PG_K_GENOTYPE = 0, 1, 2
+ABI_VERSION = 1
+
+# every symbol include/platgpu.h declares: (restype, argtypes)
+_i32p, _i64p, _f64p = C.c_void_p, C.c_void_p, C.c_void_p
+SYMBOLS = {
+    "pg_abi_version": (C.c_int, []),
+    "pg_ctx_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "pg_ctx_destroy": (C.c_int, [C.c_void_p]),
+    "pg_last_error_string": (C.c_char_p, [C.c_void_p]),
+    "pg_set_params": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_int]),
+    "pg_haps_upload": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _i64p, _i32p, _i32p]),
+    "pg_reads_upload": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _i64p, _i32p, _i32p]),
+    "pg_pairs_upload": (C.c_int, [C.c_void_p, C.c_int64, _i32p, _i32p]),
+    "pg_pairs_block": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "pg_align_launch": (C.c_int, [C.c_void_p]),
+    "pg_sync": (C.c_int, [C.c_void_p]),
+    "pg_results_fetch": (C.c_int, [C.c_void_p, _i32p, _i32p, _f64p]),
+    "pg_align_pairs": (C.c_int, [C.c_void_p, C.c_int64, _i32p, _i32p, _i32p, _i32p, _f64p]),
+    "pg_kernel_time_ms": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
+    "pg_genotype_loglik": (C.c_int, [C.c_void_p, C.c_int64, _i64p, _i64p, _i32p, _f64p]),
+}
+
+
+def load_library(path=LIB_PATH):
+    if not os.path.exists(path):
+        raise ImportError("libplatgpu.so is not built (%s): run `python -m platypus_amd.build`" % path)
+    lib = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the export is missing
+        fn.restype, fn.argtypes = res, args
+    if lib.pg_abi_version() != ABI_VERSION:
+        raise ImportError("libplatgpu.so ABI %d, binding expects %d" % (lib.pg_abi_version(), ABI_VERSION))
+    return lib
+
+
+LIB = load_library()
+
+
+class PlatGpuError(RuntimeError):
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, "libplatgpu error %d: %s" % (code, msg))
+        self.code = code
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+def _arr(a, dtype):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    return a
+
+
+class AlignContext(object):
+    """One device context (include/platgpu.h: pg_ctx)."""
+
+    def __init__(self, device=0, max_read_len=0):
+        h = C.c_void_p()
+        rc = LIB.pg_ctx_create(device, max_read_len, C.byref(h))
+        if rc != PG_OK:
+            raise PlatGpuError(rc, (LIB.pg_last_error_string(None) or b"").decode())
+        self._h = h
+        self.n_pairs = 0
+
+    def close(self):
+        if self._h is not None:
+            LIB.pg_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != PG_OK:
+            raise PlatGpuError(rc, (LIB.pg_last_error_string(self._h) or b"").decode())
+
+    def set_params(self, gapextend=3, nucprior=2, table=None):
+        if table is None:
+            table = b"NKJHFA=854210/.-,,+**))((('''&&&%%%$$$$#####\"\"\"\"\""
+        self._check(LIB.pg_set_params(self._h, gapextend, nucprior, table, len(table)))
+
+    def upload_haps(self, seq, off, start_pos, var_seq_len):
+        seq = _arr(seq, np.uint8); off = _arr(off, np.int64)
+        sp = _arr(start_pos, np.int32); vl = _arr(var_seq_len, np.int32)
+        self._check(LIB.pg_haps_upload(self._h, len(off) - 1, _ptr(seq), _ptr(off), _ptr(sp), _ptr(vl)))
+
+    def upload_reads(self, seq, qual, off, pos, mapq):
+        seq = _arr(seq, np.uint8); qual = _arr(qual, np.uint8); off = _arr(off, np.int64)
+        pos = _arr(pos, np.int32); mapq = _arr(mapq, np.int32)
+        self._check(LIB.pg_reads_upload(self._h, len(off) - 1, _ptr(seq), _ptr(qual), _ptr(off), _ptr(pos), _ptr(mapq)))
+
+    def upload_batch(self, b):
+        """Haplotypes, reads and pairs of a packed batch (see platypus_amd.synth)."""
+        self.upload_haps(b["hap_seq"], b["hap_off"], b["hap_start"], b["hap_varlen"])
+        self.upload_reads(b["read_seq"], b["read_qual"], b["read_off"], b["read_pos"], b["read_mapq"])
+        self.upload_pairs(b["pair_hap"], b["pair_read"])
+
+    def upload_pairs(self, hap_idx, read_idx):
+        hi = _arr(hap_idx, np.int32); ri = _arr(read_idx, np.int32)
+        assert len(hi) == len(ri)
+        self._check(LIB.pg_pairs_upload(self._h, len(hi), _ptr(hi), _ptr(ri)))
+        self.n_pairs = len(hi)
+
+    def pairs_block(self, hap_lo, hap_hi, read_lo, read_hi):
+        self._check(LIB.pg_pairs_block(self._h, hap_lo, hap_hi, read_lo, read_hi))
+        self.n_pairs = (hap_hi - hap_lo) * (read_hi - read_lo)
+
+    def launch(self):
+        self._check(LIB.pg_align_launch(self._h))
+
+    def sync(self):
+        self._check(LIB.pg_sync(self._h))
+
+    def fetch(self, likelihood=True):
+        n = self.n_pairs
+        score = np.empty(n, dtype=np.int32); anchor = np.empty(n, dtype=np.int32)
+        like = np.empty(n, dtype=np.float64) if likelihood else None
+        self._check(LIB.pg_results_fetch(self._h, _ptr(score), _ptr(anchor), _ptr(like)))
+        return score, anchor, like
+
+    def align_pairs(self, hap_idx, read_idx):
+        self.upload_pairs(hap_idx, read_idx)
+        if self.n_pairs == 0:
+            z = np.empty(0, dtype=np.int32)
+            return z, z.copy(), np.empty(0, dtype=np.float64)
+        self.launch()
+        return self.fetch()
+
+    def kernel_ms(self, which=PG_K_ALIGN):
+        ms = C.c_float(0)
+        self._check(LIB.pg_kernel_time_ms(self._h, which, C.byref(ms)))
+        return ms.value
+
+    def genotype_loglik(self, base1, base2, n_reads):
+        b1 = _arr(base1, np.int64); b2 = _arr(base2, np.int64); nr = _arr(n_reads, np.int32)
+        out = np.empty(len(b1), dtype=np.float64)
+        self._check(LIB.pg_genotype_loglik(self._h, len(b1), _ptr(b1), _ptr(b2), _ptr(nr), _ptr(out)))
+        return out

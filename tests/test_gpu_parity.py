@@ -1,0 +1,188 @@
+"""Parity of the HIP path (through the C ABI) with the CPU checker and with the
+golden vectors made from the reference's own compiled routine.  Integer
+results must be bit-exact; likelihoods must be the same doubles."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from platypus_amd import native
+    c = native.AlignContext(0, 1024)
+    yield c
+    c.close()
+
+
+def _oracle(b, **kw):
+    from oracle import pyoracle as po
+    from platypus_amd import synth
+    return po.run_pairs(synth.oracle_view(b), threads=8, reuse_hash=True, **kw)
+
+
+def _check_batch(ctx, b, exp_score=None, exp_anchor=None):
+    from oracle import pyoracle as po
+    ctx.upload_batch(b)
+    ctx.launch()
+    score, anchor, like = ctx.fetch()
+    if exp_score is None:
+        exp_score, exp_anchor = _oracle(b)
+    bad = np.flatnonzero(score != exp_score)
+    assert len(bad) == 0, ("score", len(bad), bad[:5], score[bad[:5]], exp_score[bad[:5]])
+    bad = np.flatnonzero(anchor != exp_anchor)
+    assert len(bad) == 0, ("anchor", len(bad), bad[:5], anchor[bad[:5]], exp_anchor[bad[:5]])
+    mq = b["read_mapq"][b["pair_read"]]
+    idx = np.linspace(0, len(score) - 1, min(len(score), 4000)).astype(int)
+    exp_like = np.array([0.0 if score[i] < 0 else po.likelihood(score[i], mq[i]) for i in idx])
+    assert np.array_equal(like[idx], exp_like)      # same doubles, not merely close
+    return score, anchor, like
+
+
+def test_golden_single_calls(ctx, golden_dir):
+    """Every golden fastAlignmentRoutine call: seq1 becomes a haplotype of
+    length len2+15 and the read is placed so that the slice starts at 0."""
+    g = np.load(os.path.join(golden_dir, "align_golden.npz"))
+    len2 = g["len2"].astype(np.int64)
+    n = len(len2)
+    b = dict(hap_seq=g["seq1"], hap_off=np.concatenate([[0], np.cumsum(len2 + 15)]).astype(np.int64),
+             hap_start=np.full(n, 500, np.int32), hap_varlen=np.zeros(n, np.int32),
+             read_seq=g["seq2"], read_qual=g["qual"],
+             read_off=np.concatenate([[0], np.cumsum(len2)]).astype(np.int64),
+             read_pos=np.full(n, 500, np.int32), read_mapq=np.full(n, 60, np.int32),
+             pair_hap=np.arange(n, dtype=np.int32), pair_read=np.arange(n, dtype=np.int32))
+    _check_batch(ctx, b, g["score"], np.zeros(n, np.int32))
+
+
+def test_golden_windows(ctx, golden_dir):
+    g = np.load(os.path.join(golden_dir, "window_golden.npz"))
+    for name in ("wgs", "panel"):
+        b = {k.split("__", 1)[1]: g[k] for k in g.files if k.startswith(name + "__")}
+        _check_batch(ctx, b, b["score"], b["anchor"])
+
+
+@pytest.mark.parametrize("kw", [
+    dict(n_windows=40, read_len=150, seed=1),
+    dict(n_windows=30, read_len=100, indel_hap_frac=0.6, seed=2),
+    dict(n_windows=30, read_len=250, hap_len=1100, indel_hap_frac=0.5, seed=3),
+    dict(n_windows=30, read_len=150, homopolymers=True, n_frac=0.005, indel_hap_frac=0.9, seed=4),
+    dict(n_windows=25, read_len=120, ragged=True, indel_hap_frac=0.5, seed=5),
+    dict(n_windows=20, read_len=36, hap_len=300, haps_per_window=7, reads_per_window=50, seed=6),
+])
+def test_synthetic_windows_vs_checker(ctx, kw):
+    from platypus_amd import synth
+    _check_batch(ctx, synth.make_batch(**kw))
+
+
+def test_edge_cases(ctx):
+    """Short reads, reads running off the haplotype end on both paths, a
+    haplotype shorter than a 7-mer, repeated 7-mers only, no votes."""
+    rng = np.random.default_rng(9)
+    A = np.frombuffer(b"ACGT", np.uint8)
+    haps, reads, quals = [], [], []
+    hstart, hvar, rpos = [], [], []
+    ph, pr = [], []
+
+    def add_hap(s, start, var):
+        haps.append(np.frombuffer(s, np.uint8) if isinstance(s, bytes) else s)
+        hstart.append(start); hvar.append(var)
+        return len(haps) - 1
+
+    def add_read(s, pos, q=30):
+        s = np.frombuffer(s, np.uint8) if isinstance(s, bytes) else s
+        reads.append(s); quals.append(np.full(len(s), q, np.uint8)); rpos.append(pos)
+        return len(reads) - 1
+
+    long_hap = A[rng.integers(0, 4, 400)]
+    h0 = add_hap(long_hap, 1000, 0)
+    h1 = add_hap(long_hap, 1000, 3)                       # same bases, forced through the vote
+    h2 = add_hap(b"ACGTACGTTGCAAGT", 1000, 2)              # 15 bases: shortest indel haplotype taken
+    h3 = add_hap(np.tile(np.frombuffer(b"AC", np.uint8), 100), 1000, 1)   # every 7-mer repeated
+    h4 = add_hap(b"ACGTACGTACGTACG", 1000, 0)
+    for L in (1, 2, 6, 7, 8, 9, 15, 16, 17, 40):
+        r = add_read(long_hap[100:100 + L].copy(), 1100)
+        for h in (h0, h1, h2, h3, h4):
+            ph.append(h); pr.append(r)
+    # runs off the end: assertion path (no indel) and N-extension path (indel)
+    for st in (330, 360, 385, 392, 399):
+        r = add_read(np.resize(long_hap[st:], 60).copy(), 1000 + st)
+        for h in (h0, h1):
+            ph.append(h); pr.append(r)
+    # read far left / far right of the haplotype start
+    for pos in (-50, 0, 1003, 1008, 5000, 2_000_000_000):
+        r = add_read(long_hap[0:50].copy(), pos)
+        for h in (h0, h1, h3):
+            ph.append(h); pr.append(r)
+    # unrelated read, all-N read, quality extremes
+    r = add_read(A[rng.integers(0, 4, 80)], 1100, 93); ph += [h0, h1]; pr += [r, r]
+    r = add_read(b"N" * 50, 1100, 0); ph += [h0, h1]; pr += [r, r]
+    r = add_read(long_hap[50:130].copy(), 1050, 127); ph += [h0, h1]; pr += [r, r]
+    b = dict(hap_seq=np.concatenate(haps),
+             hap_off=np.concatenate([[0], np.cumsum([len(h) for h in haps])]).astype(np.int64),
+             hap_start=np.array(hstart, np.int32), hap_varlen=np.array(hvar, np.int32),
+             read_seq=np.concatenate(reads), read_qual=np.concatenate(quals),
+             read_off=np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.int64),
+             read_pos=np.array(rpos, np.int32), read_mapq=np.full(len(reads), 37, np.int32),
+             pair_hap=np.array(ph, np.int32), pair_read=np.array(pr, np.int32))
+    score, anchor, like = _check_batch(ctx, b)
+    assert (score == -1).any() and (like[score == -1] == 0.0).all()
+
+
+def test_custom_parameters(ctx):
+    from platypus_amd import synth
+    b = synth.make_batch(n_windows=10, read_len=100, homopolymers=True, indel_hap_frac=0.5, seed=21)
+    tab = bytes([33 + v for v in (50, 40, 35, 30, 22, 15, 9, 4)])
+    try:
+        ctx.set_params(5, 1, tab)
+        exp = _oracle(b, gapextend=5, nucprior=1, table=tab)
+        _check_batch(ctx, b, *exp)
+    finally:
+        ctx.set_params()
+
+
+def test_dense_block_and_errors(ctx):
+    from platypus_amd import native, synth
+    b = synth.make_batch(n_windows=3, reads_per_window=10, read_len=80, hap_len=400, seed=31)
+    ctx.upload_batch(b)
+    ctx.pairs_block(4, 8, 10, 20)               # window 1: haplotypes 4..7 x reads 10..19
+    ctx.launch()
+    s, a, _ = ctx.fetch()
+    ctx.upload_pairs(b["pair_hap"], b["pair_read"])
+    ctx.launch()
+    s_all, a_all, _ = ctx.fetch()
+    sel = (b["pair_hap"] >= 4) & (b["pair_hap"] < 8)
+    assert np.array_equal(s, s_all[sel]) and np.array_equal(a, a_all[sel])
+    with pytest.raises(native.PlatGpuError) as e:
+        ctx.upload_haps(np.frombuffer(b"ACGTA", np.uint8), [0, 5], [0], [2])
+    assert e.value.code == native.PG_ERR_UNSUPPORTED
+    ctx.upload_batch(b)
+    with pytest.raises(native.PlatGpuError) as e:
+        ctx.upload_pairs([0, 99999], [0, 0])
+    assert e.value.code == native.PG_ERR_INVALID
+    bad_q = b["read_qual"].copy(); bad_q[5] = 200
+    with pytest.raises(native.PlatGpuError) as e:
+        ctx.upload_reads(b["read_seq"], bad_q, b["read_off"], b["read_pos"], b["read_mapq"])
+    assert e.value.code == native.PG_ERR_UNSUPPORTED
+    ctx.upload_reads(b["read_seq"], b["read_qual"], b["read_off"], b["read_pos"], b["read_mapq"])
+    s0, a0, l0 = ctx.align_pairs(np.zeros(0, np.int32), np.zeros(0, np.int32))
+    assert len(s0) == 0 and len(a0) == 0 and len(l0) == 0
+
+
+def test_genotype_loglik(ctx):
+    from oracle import pyoracle as po
+    from platypus_amd import synth
+    b = synth.make_batch(n_windows=6, haps_per_window=4, reads_per_window=37, read_len=100, seed=41)
+    ctx.upload_batch(b)
+    ctx.launch()
+    _, _, like = ctx.fetch()
+    H, R = 4, 37
+    b1, b2 = [], []
+    for w in range(6):
+        for i in range(H):
+            for j in range(i, H):
+                b1.append((w * H + i) * R); b2.append((w * H + j) * R)
+    got = ctx.genotype_loglik(b1, b2, np.full(len(b1), R, np.int32))
+    exp = np.array([po.genotype_loglik(like[x:x + R], like[y:y + R]) for x, y in zip(b1, b2)])
+    assert np.all(np.abs(got - exp) <= 1e-9 * np.abs(exp) + 1e-300)   # 1e-9 relative
