@@ -151,6 +151,15 @@ int pg_kernel_time_ms(pg_ctx *ctx, int which, float *ms);
 int pg_genotype_loglik(pg_ctx *ctx, int64_t n_gen, const int64_t *pair_base1,
                        const int64_t *pair_base2, const int32_t *n_reads, double *out);
 
+/*
+ * Measured issue rate of the packed 16-bit integer VALU instructions the
+ * alignment kernel is built from (v_pk_add_u16 / v_pk_min_i16), in int16
+ * operations per second (one packed instruction on one lane = 2 operations).
+ * The denominator of the kernel's roofline fraction.  No counterpart in the
+ * reference.  Invalidates the results of the last launch.
+ */
+int pg_valu_int16_peak(pg_ctx *ctx, double *ops_per_second);
+
 #ifdef __cplusplus
 }
 #endif

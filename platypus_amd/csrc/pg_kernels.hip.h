@@ -421,4 +421,27 @@ __global__ __launch_bounds__(256) void k_genotype(const double* __restrict__ lik
     if (lane == 0) out[g] = s;
 }
 
+// ---------------------------------------------------------------------------
+// k_pk_rate: issue-rate probe for the packed int16 VALU instructions the DP is
+// made of (v_pk_add_u16 / v_pk_min_i16).  16 independent dependency chains per
+// lane, 2 instructions per chain step; nothing touches memory inside the loop.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pk_rate(uint32_t* __restrict__ out, int iters, uint32_t b, uint32_t c)
+{
+    uint32_t a[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = threadIdx.x * 0x00010003u + i;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) a[i] = pk_min_i(pk_add(a[i], b), c);
+        }
+    }
+    uint32_t x = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x ^= a[i];
+    out[blockIdx.x * 256 + threadIdx.x] = x;
+}
+
 }  // namespace pg

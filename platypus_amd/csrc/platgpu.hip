@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <type_traits>
@@ -13,6 +14,7 @@
 
 #include "../../include/platgpu.h"
 #include "pg_kernels.hip.h"
+#include "pg_align.hip.h"
 
 namespace {
 
@@ -47,6 +49,8 @@ struct pg_ctx {
     int gapextend = 3, nucprior = 2;
     std::string table;
     DevBuf<int16_t> d_tab4;
+    DevBuf<uint8_t> d_tab1;              // table[h] - 33
+    int align_kernel = 2;                // PG_ALIGN_KERNEL=1 selects the packed-int16 kernel (A/B runs)
     DevBuf<double> d_exp_score, d_exp_mapq;
 
     // haplotypes
@@ -54,7 +58,8 @@ struct pg_ctx {
     int max_hap_len = 0;
     std::vector<int64_t> h_hap_off;      // host offsets (lengths)
     std::vector<int32_t> h_hap_varlen;
-    DevBuf<uint8_t> d_hap_raw, d_hap, d_run;
+    DevBuf<uint8_t> d_hap_raw, d_hap, d_run, d_hap_has_n;
+    DevBuf<uint16_t> d_hapx;
     DevBuf<int64_t> d_hap_soff, d_hap_doff;
     DevBuf<int32_t> d_hap_len, d_hap_start, d_hap_varlen;
 
@@ -64,7 +69,8 @@ struct pg_ctx {
     bool uniform_rlen = true;
     std::vector<int64_t> h_read_off;
     DevBuf<uint8_t> d_rseq, d_rqual;
-    DevBuf<int64_t> d_roff;
+    DevBuf<uint16_t> d_readx;
+    DevBuf<int64_t> d_roff, d_read_xoff;
     DevBuf<int32_t> d_read_pos, d_read_mapq;
 
     // pairs
@@ -115,8 +121,12 @@ int upload_params(pg_ctx* c) {
         const int ch = (unsigned char)c->table[std::min(i, n - 1)];
         tab4[i] = (int16_t)(4 * (ch - '!'));      // align.c:85
     }
+    uint8_t tab1[256];
+    for (int i = 0; i < 256; ++i) tab1[i] = (uint8_t)(tab4[i] / 4);
     PG_HIP(c, c->d_tab4.reserve(256));
+    PG_HIP(c, c->d_tab1.reserve(256));
     PG_HIP(c, hipMemcpyAsync(c->d_tab4.p, tab4, sizeof tab4, hipMemcpyHostToDevice, c->stream));
+    PG_HIP(c, hipMemcpyAsync(c->d_tab1.p, tab1, sizeof tab1, hipMemcpyHostToDevice, c->stream));
     // likelihood factors with the host C library, so the device result is the
     // same double the reference computes (calign.pyx:17,55,63)
     const double mLTOT = -0.23025850929940459;
@@ -162,6 +172,7 @@ int pg_ctx_create(int device_ordinal, int max_read_len, pg_ctx** out) {
     c->device = device_ordinal;
     c->max_read_len = max_read_len;
     c->table = kDefaultTable;
+    if (const char* k = std::getenv("PG_ALIGN_KERNEL")) c->align_kernel = std::atoi(k) == 1 ? 1 : 2;
     if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
         delete c;
         return fail(nullptr, PG_ERR_HIP, "cannot create a stream on device %d", device_ordinal);
@@ -178,7 +189,9 @@ int pg_ctx_destroy(pg_ctx* c) {
     if (!c) return PG_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    c->d_tab4.release(); c->d_exp_score.release(); c->d_exp_mapq.release();
+    c->d_tab4.release(); c->d_tab1.release(); c->d_hap_has_n.release(); c->d_hapx.release();
+    c->d_readx.release(); c->d_read_xoff.release();
+    c->d_exp_score.release(); c->d_exp_mapq.release();
     c->d_hap_raw.release(); c->d_hap.release(); c->d_run.release();
     c->d_hap_soff.release(); c->d_hap_doff.release();
     c->d_hap_len.release(); c->d_hap_start.release(); c->d_hap_varlen.release();
@@ -198,8 +211,8 @@ int pg_set_params(pg_ctx* c, int gapextend, int nucprior, const char* table, int
     if (!c) return PG_ERR_INVALID;
     if (!table || table_len < 1 || table_len > 255)
         return fail(c, PG_ERR_INVALID, "gap-open table must hold 1..255 characters");
-    if (gapextend < 0 || gapextend > 255 || nucprior < 0 || nucprior > 255)
-        return fail(c, PG_ERR_INVALID, "gapextend/nucprior outside 0..255");
+    if (gapextend < 0 || gapextend > 64 || nucprior < 0 || nucprior > 64)
+        return fail(c, PG_ERR_INVALID, "gapextend/nucprior outside 0..64");
     for (int i = 0; i < table_len; ++i)
         if ((unsigned char)table[i] < '!' || (unsigned char)table[i] > '~')
             return fail(c, PG_ERR_INVALID, "gap-open table character %d is not phred+33", i);
@@ -221,7 +234,7 @@ int pg_haps_upload(pg_ctx* c, int n, const char* seq, const int64_t* off,
     PG_HIP(c, hipSetDevice(c->device));
     c->n_haps = 0; c->n_pairs = 0; c->launched = false;
     if (n == 0) return PG_OK;
-    const int pad = c->max_read_len + 32;
+    const int pad = c->max_read_len + 64;
     std::vector<int64_t> doff(n + 1);
     std::vector<int32_t> len(n);
     int maxlen = 0;
@@ -242,6 +255,8 @@ int pg_haps_upload(pg_ctx* c, int n, const char* seq, const int64_t* off,
     PG_HIP(c, c->d_hap_raw.reserve((size_t)total + 16));
     PG_HIP(c, c->d_hap.reserve((size_t)doff[n] + 64));
     PG_HIP(c, c->d_run.reserve((size_t)doff[n] + 64));
+    PG_HIP(c, c->d_hapx.reserve((size_t)doff[n] + 64));
+    PG_HIP(c, c->d_hap_has_n.reserve(n));
     PG_HIP(c, c->d_hap_soff.reserve(n + 1));
     PG_HIP(c, c->d_hap_doff.reserve(n + 1));
     PG_HIP(c, c->d_hap_len.reserve(n));
@@ -259,6 +274,9 @@ int pg_haps_upload(pg_ctx* c, int n, const char* seq, const int64_t* off,
     const int grid = std::min(n, 65536);
     hipLaunchKernelGGL(pg::k_pack_haps, dim3(grid), dim3(256), 0, c->stream, c->d_hap_raw.p, c->d_hap_soff.p,
                        c->d_hap_doff.p, c->d_hap.p, c->d_run.p, n, pad, cap);
+    PG_HIP(c, hipGetLastError());
+    hipLaunchKernelGGL(pg::k_pack_hapx, dim3(grid), dim3(256), 0, c->stream, c->d_hap_raw.p, c->d_hap_soff.p,
+                       c->d_hap_doff.p, c->d_hapx.p, c->d_hap_has_n.p, n, pad, cap);
     PG_HIP(c, hipGetLastError());
     PG_HIP(c, hipStreamSynchronize(c->stream));   // host vectors above go out of scope
     c->h_hap_off.assign(soff.begin(), soff.end());
@@ -298,13 +316,21 @@ int pg_reads_upload(pg_ctx* c, int n, const char* seq, const char* qual, const i
     PG_HIP(c, c->d_roff.reserve(n + 1));
     PG_HIP(c, c->d_read_pos.reserve(n));
     PG_HIP(c, c->d_read_mapq.reserve(n));
-    std::vector<int64_t> roff(n + 1);
+    std::vector<int64_t> roff(n + 1), xoff(n + 1);
     for (int i = 0; i <= n; ++i) roff[i] = off[i] - off[0];
+    xoff[0] = 0;                                   // 8-element aligned rows with >= 24 padding elements
+    for (int i = 0; i < n; ++i) xoff[i + 1] = xoff[i] + ((roff[i + 1] - roff[i] + 7) / 8) * 8 + 24;
+    PG_HIP(c, c->d_readx.reserve((size_t)xoff[n] + 64));
+    PG_HIP(c, c->d_read_xoff.reserve(n + 1));
+    PG_HIP(c, hipMemcpyAsync(c->d_read_xoff.p, xoff.data(), (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
     PG_HIP(c, hipMemcpyAsync(c->d_rseq.p, seq + off[0], (size_t)total, hipMemcpyHostToDevice, c->stream));
     PG_HIP(c, hipMemcpyAsync(c->d_rqual.p, qual + off[0], (size_t)total, hipMemcpyHostToDevice, c->stream));
     PG_HIP(c, hipMemcpyAsync(c->d_roff.p, roff.data(), (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
     PG_HIP(c, hipMemcpyAsync(c->d_read_pos.p, pos, n * 4, hipMemcpyHostToDevice, c->stream));
     PG_HIP(c, hipMemcpyAsync(c->d_read_mapq.p, mapq, n * 4, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(pg::k_pack_readx, dim3(std::min((n + 3) / 4, 65536)), dim3(256), 0, c->stream, c->d_rseq.p,
+                       c->d_rqual.p, c->d_roff.p, c->d_read_xoff.p, c->d_readx.p, n);
+    PG_HIP(c, hipGetLastError());
     PG_HIP(c, hipStreamSynchronize(c->stream));
     c->h_read_off.swap(roff);
     c->max_rlen = maxl;
@@ -445,8 +471,21 @@ int pg_align_launch(pg_ctx* c) {
     A.exp_score = c->d_exp_score.p; A.exp_mapq = c->d_exp_mapq.p;
     A.score = c->d_score.p; A.anchor = c->d_anchor.p; A.like = c->d_like.p;
     A.n_waves = c->n_waves; A.ge4 = 4 * c->gapextend; A.np4 = 4 * c->nucprior;
+    pg::Align2Args B;
+    B.hapx = c->d_hapx.p; B.hap_xoff = c->d_hap_doff.p; B.hap_len = c->d_hap_len.p;
+    B.hap_start = c->d_hap_start.p; B.hap_varlen = c->d_hap_varlen.p; B.hap_has_n = c->d_hap_has_n.p;
+    B.readx = c->d_readx.p; B.read_xoff = c->d_read_xoff.p;
+    B.read_pos = c->d_read_pos.p; B.read_mapq = c->d_read_mapq.p;
+    B.pair_hap = c->d_pair_hap.p; B.pair_read = c->d_pair_read.p; B.order = A.order;
+    B.waves = c->d_waves.p; B.anchor_in = c->d_anchor_in.p; B.tab = c->d_tab1.p;
+    B.exp_score = c->d_exp_score.p; B.exp_mapq = c->d_exp_mapq.p;
+    B.score = c->d_score.p; B.anchor = c->d_anchor.p; B.like = c->d_like.p;
+    B.n_waves = c->n_waves; B.ge = c->gapextend; B.np = c->nucprior;
     PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_ALIGN], c->stream));
-    hipLaunchKernelGGL(pg::k_align, dim3((c->n_waves + 3) / 4), dim3(256), 0, c->stream, A);
+    if (c->align_kernel == 1)
+        hipLaunchKernelGGL(pg::k_align, dim3((c->n_waves + 3) / 4), dim3(256), 0, c->stream, A);
+    else
+        hipLaunchKernelGGL(pg::k_align2, dim3((c->n_waves + 3) / 4), dim3(256), 0, c->stream, B);
     PG_HIP(c, hipGetLastError());
     PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_ALIGN + 1], c->stream));
     c->ev_valid[PG_K_ALIGN] = true;
@@ -516,6 +555,34 @@ int pg_genotype_loglik(pg_ctx* c, int64_t ng, const int64_t* b1, const int64_t* 
     c->ev_valid[PG_K_GENOTYPE] = true;
     PG_HIP(c, hipMemcpyAsync(out, c->d_gout.p, ng * 8, hipMemcpyDeviceToHost, c->stream));
     PG_HIP(c, hipStreamSynchronize(c->stream));
+    return PG_OK;
+}
+
+int pg_valu_int16_peak(pg_ctx* c, double* ops_per_second) {
+    if (!c || !ops_per_second) return PG_ERR_INVALID;
+    PG_HIP(c, hipSetDevice(c->device));
+    const int blocks = 256 * 8, iters = 4096;      // 8 workgroups of 4 wavefronts per CU
+    PG_HIP(c, c->d_score.reserve((size_t)blocks * 256));
+    uint32_t* out = reinterpret_cast<uint32_t*>(c->d_score.p);
+    hipEvent_t e0, e1;
+    PG_HIP(c, hipEventCreate(&e0));
+    PG_HIP(c, hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int rep = 0; rep < 4; ++rep) {            // first repetition warms up
+        PG_HIP(c, hipEventRecord(e0, c->stream));
+        hipLaunchKernelGGL(pg::k_pk_rate, dim3(blocks), dim3(256), 0, c->stream, out, iters, 0x00030005u, 0x7ff07ff1u);
+        PG_HIP(c, hipEventRecord(e1, c->stream));
+        PG_HIP(c, hipEventSynchronize(e1));
+        float ms = 0;
+        PG_HIP(c, hipEventElapsedTime(&ms, e0, e1));
+        if (rep > 0 && ms < best) best = ms;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    c->launched = false;                           // the probe used the score buffer
+    // per lane: iters * 8 * 16 chain steps * 2 instructions * 2 int16 operations
+    const double ops = (double)blocks * 256.0 * iters * 8.0 * 16.0 * 2.0 * 2.0;
+    *ops_per_second = ops / (best * 1e-3);
     return PG_OK;
 }
 

@@ -35,6 +35,7 @@ SYMBOLS = {
     "pg_align_pairs": (C.c_int, [C.c_void_p, C.c_int64, _i32p, _i32p, _i32p, _i32p, _f64p]),
     "pg_kernel_time_ms": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
     "pg_genotype_loglik": (C.c_int, [C.c_void_p, C.c_int64, _i64p, _i64p, _i32p, _f64p]),
+    "pg_valu_int16_peak": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
 }
 
 
@@ -150,6 +151,11 @@ class AlignContext(object):
         ms = C.c_float(0)
         self._check(LIB.pg_kernel_time_ms(self._h, which, C.byref(ms)))
         return ms.value
+
+    def valu_int16_peak(self):
+        v = C.c_double(0)
+        self._check(LIB.pg_valu_int16_peak(self._h, C.byref(v)))
+        return v.value
 
     def genotype_loglik(self, base1, base2, n_reads):
         b1 = _arr(base1, np.int64); b2 = _arr(base2, np.int64); nr = _arr(n_reads, np.int32)
