@@ -35,6 +35,14 @@ constexpr uint32_t kPadElem = ('0' << 8) | 64;   // align.c:119-120, packed as (
 typedef uint16_t u16;
 __device__ __forceinline__ u16 add16(u16 a, u16 b) { return (u16)(a + b); }
 __device__ __forceinline__ u16 min16(u16 a, u16 b) { return a < b ? a : b; }
+// Hide how a value was made, so that the compiler cannot fold its producer into
+// the consumer as a three-operand instruction (v_bitop3_b16, v_min3_u16: half /
+// quarter rate on gfx950).  Emits nothing.
+__device__ __forceinline__ u16 opaque(u16 x) {
+    uint32_t v = x;
+    asm volatile("" : "+v"(v));
+    return (u16)v;
+}
 // a uniform value the compiler must keep in a VGPR
 __device__ __forceinline__ u16 in_vgpr(uint32_t x) {
     uint32_t d;
@@ -64,36 +72,66 @@ struct Align2Args {
     int32_t* score;
     int32_t* anchor;
     double* like;
+    int32_t* n_list;           // wavefronts left to the 'N'-aware kernel
+    int32_t* n_count;
     int n_waves;
     int ge, np;
 };
 
+// Per-lane state.  Every DP value is kept with an offset of P*d added, where
+// d is the diagonal of the cell (even lane k: d = 2k, odd lane k: d = 2k+1) and
+// P = gapextend + nucprior.  A move along I steps one diagonal down, so its
+// "+ P" (align.c:169-173: gap_extend, then nuc_prior) cancels against the
+// offset and  I' = min(I + ge, M + G) + np  becomes  I' = min(I, M + (G - ge)):
+// one instruction less per cell.  A move along D steps one diagonal up and pays
+// the offset once more: D' = min(D + (ge + P), u + (G + P)).  M stays on its
+// diagonal.  Offsets are removed where scores are picked up.  All of this is
+// exact integer arithmetic (no value comes near 2^16).
 struct Lane2 {
-    u16 u1[8], d1[8], m2[8], i2[8], d2[8], u2[8];
-    u16 s1[8], s2[8], q[8], g[8], gn[8], nq[8];
+    u16 m1g[8];                      // min(M1, I1, D1) of the even lanes, ready for the next even half-step
+    u16 m2[8], i2[8], d2[8], u2[8];  // odd lanes; u2 = min(m2, i2)
+    u16 s1[8], s2[8], q[8];          // rings: haplotype bases, read bases, read qualities
+    u16 gP[8], gM[8];                // rings: gap-open + P (for D), gap-open - ge (for I)
+    u16 nq[8];                       // ring: 'N' limit of the haplotype column (HASN only)
     u16 best;
 };
 
-// min(best, v[j]) for a wave-uniform j, written so that no lane of v is ever
-// addressed dynamically (the compiler would park the array in scratch): every
-// lane but j is pushed to 0xffff before the minimum.
-__device__ __forceinline__ u16 take_min(u16 best, const u16 (&v)[8], int j) {
+// min(best, v[j] - off(j)) for a wave-uniform j, written so that no lane of v is
+// ever addressed dynamically (the compiler would park the array in scratch):
+// every lane but j is pushed to 0xffff before the minimum.
+template <int ODD>
+__device__ __forceinline__ u16 take_min(u16 best, const u16 (&v)[8], int j, uint32_t P) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) best = min16(best, (u16)(v[k] | (j == k ? (u16)0 : (u16)0xffff)));
+    for (int k = 0; k < 8; ++k) {
+        const u16 cand = (u16)(v[k] - (u16)((2 * k + ODD) * P));
+        best = min16(best, (u16)(cand | (j == k ? (u16)0 : (u16)0xffff)));
+    }
     return best;
 }
 
+struct Consts2 {
+    u16 geP;      // ge + P
+    u16 P;        // ge + np
+    u16 mge;      // -ge (mod 2^16)
+    u16 inf;      // pos_inf
+    u16 inf15;    // pos_inf + 15 P
+    uint32_t Ps;  // P again, as a scalar
+};
+
 // One iteration t (t & 7 == J) of the loop at align.c:106-232.
 //   re  read element of position t, he  haplotype element of slice position t+8
-template <int J, bool HASN>
+// EDGE iterations carry the start-up (t < 8, align.c:127-128) and the score
+// pick-up (t >= len2, align.c:134-156,195-217); the others need neither.
+template <int J, bool HASN, bool EDGE>
 __device__ __forceinline__ void dp_iter(Lane2& L, int t, int len2, int e, uint32_t re, uint32_t he,
-                                        const uint8_t* s_tab, u16 ge, u16 genp, u16 np, u16 inf)
+                                        const uint8_t* s_tab, const Consts2& C)
 {
     // align.c:111-121: the read window takes position t
-    L.s2[J] = (u16)(re & 0xff00u);
-    L.q[J] = (u16)(re & 0x00ffu);
-    if (t < 8) {                      // align.c:127-128: lane t starts at cost 0
-        L.u1[J] = 0; L.m2[J] = 0; L.u2[J] = 0;
+    L.s2[J] = opaque((u16)(re & 0xff00u));
+    L.q[J] = opaque((u16)(re & 0x00ffu));
+    if (EDGE && t < 8) {              // align.c:127-128: lane t (== J here) starts at cost 0
+        L.m1g[J] = (u16)(2 * J * C.Ps);
+        L.m2[J] = L.u2[J] = (u16)((2 * J + 1) * C.Ps);
     }
     // gap-open of slice position t+8 (align.c:85,186): run length cut at the slice end
     const int room = e - 8 - t;
@@ -101,117 +139,132 @@ __device__ __forceinline__ void dp_iter(Lane2& L, int t, int len2, int e, uint32
     const u16 gnew = s_tab[hrun];
 
     // ---- even half-step, align.c:129-173 ----
-    u16 m1[8], i1[8], d1n[8], u1n[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) m1[k] = min16(L.u1[k], L.d1[k]);
-    if (t >= len2) L.best = take_min(L.best, m1, t - len2);     // align.c:134-156
+    if (EDGE && t >= len2) L.best = take_min<0>(L.best, L.m1g, t - len2, C.Ps);   // align.c:134-156
+    u16 m1[8], i1[8], u1[8], d1n[8], m2g[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         u16 c = min16((u16)(L.s2[(J - k) & 7] ^ L.s1[(J + k) & 7]), L.q[(J - k) & 7]);
-        if (HASN) c = min16(c, L.nq[(J + k) & 7]);
-        m1[k] = add16(m1[k], c);
-        i1[k] = min16(add16(L.i2[k], genp), add16(L.m2[k], L.gn[(J + 7 - k) & 7]));
-        u1n[k] = min16(m1[k], i1[k]);
+        if (HASN) c = min16(opaque(c), L.nq[(J + k) & 7]);
+        m1[k] = add16(L.m1g[k], c);
+        i1[k] = min16(L.i2[k], add16(L.m2[k], L.gM[(J + 7 - k) & 7]));
+        if (k == 0) i1[k] = opaque(i1[k]);       // its only reader is the next line
+        u1[k] = min16(m1[k], i1[k]);
     }
-    d1n[0] = inf;                     // align.c:168
+    d1n[0] = C.inf;                   // align.c:168
 #pragma unroll
     for (int k = 1; k < 8; ++k)
-        d1n[k] = min16(add16(L.d2[k - 1], ge), add16(L.u2[k - 1], L.g[(J + 8 - k) & 7]));
+        d1n[k] = min16(add16(L.d2[k - 1], C.geP), add16(L.u2[k - 1], L.gP[(J + 8 - k) & 7]));
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m2g[k] = min16(L.u2[k], L.d2[k]);                // align.c:190
 
     // ---- align.c:180-187: haplotype window, N limits and gap-open vector take position t+8 ----
-    L.s1[J] = (u16)(he & 0xff00u);
-    if (HASN) L.nq[J] = ((he & 0xff00u) == ((uint32_t)'N' << 8)) ? (u16)1 : inf;
-    L.g[J] = gnew;
-    L.gn[J] = add16(gnew, np);
+    L.s1[J] = opaque((u16)(he & 0xff00u));
+    if (HASN) L.nq[J] = ((he & 0xff00u) == ((uint32_t)'N' << 8)) ? (u16)1 : C.inf;
+    L.gP[J] = add16(gnew, C.P);
+    L.gM[J] = add16(gnew, C.mge);
 
     // ---- odd half-step, align.c:190-231 ----
-    u16 m2n[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) m2n[k] = min16(L.u2[k], L.d2[k]);
-    if (t >= len2) L.best = take_min(L.best, m2n, t - len2);    // align.c:195-217
+    if (EDGE && t >= len2) L.best = take_min<1>(L.best, m2g, t - len2, C.Ps);     // align.c:195-217
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         u16 c = min16((u16)(L.s2[(J - k) & 7] ^ L.s1[(J + 1 + k) & 7]), L.q[(J - k) & 7]);
-        if (HASN) c = min16(c, L.nq[(J + 1 + k) & 7]);
-        L.m2[k] = add16(m2n[k], c);
-        L.d2[k] = min16(add16(d1n[k], ge), add16(u1n[k], L.g[(J + 8 - k) & 7]));
+        if (HASN) c = min16(opaque(c), L.nq[(J + 1 + k) & 7]);
+        L.m2[k] = add16(m2g[k], c);
+        L.d2[k] = min16(add16(d1n[k], C.geP), add16(u1[k], L.gP[(J + 8 - k) & 7]));
+        L.m1g[k] = min16(u1[k], d1n[k]);                                          // align.c:129, next iteration
     }
 #pragma unroll
-    for (int k = 0; k < 7; ++k)
-        L.i2[k] = min16(add16(i1[k + 1], genp), add16(m1[k + 1], L.gn[(J + 7 - k) & 7]));
-    L.i2[7] = inf;                    // align.c:230
+    for (int k = 0; k < 7; ++k) L.i2[k] = min16(i1[k + 1], add16(m1[k + 1], L.gM[(J + 7 - k) & 7]));
+    L.i2[7] = C.inf15;                // align.c:230
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        L.u2[k] = min16(L.m2[k], L.i2[k]);
-        L.u1[k] = u1n[k];
-        L.d1[k] = d1n[k];
-    }
+    for (int k = 0; k < 8; ++k) L.u2[k] = min16(L.m2[k], L.i2[k]);
 }
 
-__device__ __forceinline__ uint32_t elem16(const uint4& b, int j) {
-    const uint32_t w = (j >> 1) == 0 ? b.x : (j >> 1) == 1 ? b.y : (j >> 1) == 2 ? b.z : b.w;
+__device__ __forceinline__ uint32_t elem4(const uint2& b, int j) {   // element j (0..3) of four packed u16
+    const uint32_t w = (j >> 1) == 0 ? b.x : b.y;
     return (j & 1) ? (w >> 16) : (w & 0xffffu);
 }
-__device__ __forceinline__ uint4 load16_unaligned(const uint16_t* p) {
-    uint4 v;
-    __builtin_memcpy(&v, p, 16);
+__device__ __forceinline__ uint2 load8_unaligned(const uint16_t* p) {
+    uint2 v;
+    __builtin_memcpy(&v, p, 8);
     return v;
+}
+
+// Eight iterations tb .. tb+7.  The element buffers roll: the low halves hold
+// positions tb..tb+3 on entry, the high halves are fetched here for tb+4..tb+7,
+// and the low halves are refetched for the next block while the high halves
+// are in use -- every load has four iterations to land.
+template <bool HASN, bool EDGE>
+__device__ __forceinline__ void dp_block(Lane2& L, int tb, int iters, int len2, int e,
+                                         const uint16_t* rx, const uint16_t* hx8,
+                                         uint2& rlo, uint2& hlo, const uint8_t* s_tab, const Consts2& C)
+{
+    const uint2 rhi = *reinterpret_cast<const uint2*>(rx + tb + 4);
+    const uint2 hhi = load8_unaligned(hx8 + tb + 4);
+#define PG_IT(J, RB, HB)                                                                        \
+    if (!EDGE || tb + J < iters)                                                                \
+        dp_iter<J, HASN, EDGE>(L, tb + J, len2, e, elem4(RB, J & 3), elem4(HB, J & 3), s_tab, C);
+    PG_IT(0, rlo, hlo) PG_IT(1, rlo, hlo) PG_IT(2, rlo, hlo) PG_IT(3, rlo, hlo)
+    rlo = *reinterpret_cast<const uint2*>(rx + tb + 8);
+    hlo = load8_unaligned(hx8 + tb + 8);
+    PG_IT(4, rhi, hhi) PG_IT(5, rhi, hhi) PG_IT(6, rhi, hhi) PG_IT(7, rhi, hhi)
+#undef PG_IT
 }
 
 template <bool HASN>
 __device__ __forceinline__ u16 align_pair(const uint16_t* hx, const uint16_t* rx, int len2,
-                                               const uint8_t* s_tab, uint32_t ge_, uint32_t np_)
+                                          const uint8_t* s_tab, uint32_t ge_, uint32_t np_)
 {
     const int len1 = len2 + 15, e = len1 - 1;
-    const u16 ge = in_vgpr(ge_), np = in_vgpr(np_), genp = in_vgpr(ge_ + np_), inf = in_vgpr(kInf);
+    const uint32_t P = ge_ + np_;
+    Consts2 C;
+    C.geP = in_vgpr(ge_ + P); C.P = in_vgpr(P); C.mge = in_vgpr(0u - ge_);
+    C.inf = in_vgpr(kInf); C.inf15 = in_vgpr(kInf + 15 * P); C.Ps = P;
     Lane2 L;
-    const uint4 h0 = load16_unaligned(hx);
+    const uint2 h0 = load8_unaligned(hx), h1 = load8_unaligned(hx + 4);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        L.u1[k] = L.d1[k] = L.m2[k] = L.i2[k] = L.d2[k] = L.u2[k] = inf;   // align.c:53-58
+        L.m1g[k] = (u16)(kInf + 2 * k * P);                                  // align.c:53-58
+        L.m2[k] = L.i2[k] = L.d2[k] = L.u2[k] = (u16)(kInf + (2 * k + 1) * P);
         L.s2[k] = kS2Init;                                                   // align.c:64
         L.q[k] = 64;                                                         // align.c:65
-        const uint32_t he = elem16(h0, k);
+        const uint32_t he = k < 4 ? elem4(h0, k & 3) : elem4(h1, k & 3);
         L.s1[k] = (u16)(he & 0xff00u);                                       // align.c:63
-        L.nq[k] = inf;                // align.c:68: no 'N' discount inside the first 8 columns
-        // align.c:100 with the window written as a ring: slot j holds the entry that
-        // reaches lane k at iteration t when (t + 7 - k) & 7 == j, i.e. position 7-j now
+        L.nq[k] = kInf;               // align.c:68: no 'N' discount inside the first 8 columns
     }
+    // align.c:100 with the window written as a ring: slot j holds the entry that
+    // reaches lane k at iteration t when (t + 7 - k) & 7 == j, i.e. slice position 7-j now
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int pos = 7 - j;
-        const uint32_t run = elem16(h0, pos) & 0xffu;
+        const uint32_t run = (pos < 4 ? elem4(h0, pos & 3) : elem4(h1, pos & 3)) & 0xffu;
         const uint32_t hr = run < (uint32_t)(e - pos) ? run : (uint32_t)(e - pos);
-        L.g[j] = s_tab[hr];
-        L.gn[j] = (u16)(L.g[j] + np_);
+        const uint32_t g = s_tab[hr];
+        L.gP[j] = (u16)(g + P);
+        L.gM[j] = (u16)(g - ge_);
     }
-    L.best = inf;                                                            // align.c:34
+    L.best = kInf;                                                           // align.c:34
 
     const int iters = len2 + 8;                                              // align.c:106
-    uint4 rb = *reinterpret_cast<const uint4*>(rx);
-    uint4 hb = load16_unaligned(hx + 8);
-    for (int tb = 0; tb < iters; tb += 8) {
-        const uint4 rb_next = *reinterpret_cast<const uint4*>(rx + tb + 8);
-        const uint4 hb_next = load16_unaligned(hx + 16 + tb);
-#define PG_IT(J)                                                                                  \
-        if (tb + J < iters)                                                                       \
-            dp_iter<J, HASN>(L, tb + J, len2, e, elem16(rb, J), elem16(hb, J), s_tab, ge, genp, np, inf);
-        PG_IT(0) PG_IT(1) PG_IT(2) PG_IT(3) PG_IT(4) PG_IT(5) PG_IT(6) PG_IT(7)
-#undef PG_IT
-        rb = rb_next;
-        hb = hb_next;
-    }
+    const uint16_t* hx8 = hx + 8;
+    uint2 rlo = *reinterpret_cast<const uint2*>(rx);
+    uint2 hlo = load8_unaligned(hx8);
+    int tb = 0;
+    dp_block<HASN, true>(L, tb, iters, len2, e, rx, hx8, rlo, hlo, s_tab, C);
+    for (tb = 8; tb + 8 <= len2; tb += 8)
+        dp_block<HASN, false>(L, tb, iters, len2, e, rx, hx8, rlo, hlo, s_tab, C);
+    for (; tb < iters; tb += 8)
+        dp_block<HASN, true>(L, tb, iters, len2, e, rx, hx8, rlo, hlo, s_tab, C);
     return L.best;
 }
 
-__global__ __launch_bounds__(256) void k_align2(const Align2Args A)
+// The fast kernel (no 'N' handling, 128 VGPRs, 4 wavefronts per SIMD) takes every
+// wavefront; one whose pairs may meet an 'N' (the haplotype has one, or the
+// slice reaches the 'N' padding) only appends itself to `n_list` and leaves.
+// The second kernel walks that list with the full recurrence.
+template <bool HASN>
+__device__ __forceinline__ void align_wave(const Align2Args& A, int wave, const uint8_t* s_tab)
 {
-    __shared__ uint8_t s_tab[256];
-    s_tab[threadIdx.x] = A.tab[threadIdx.x];
-    __syncthreads();
-
-    const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256u + threadIdx.x) >> 6));
-    if (wave >= A.n_waves) return;
     const int lane = threadIdx.x & 63;
     const int w_first = __builtin_amdgcn_readfirstlane(A.waves[wave].first);
     const int w_count = __builtin_amdgcn_readfirstlane(A.waves[wave].count);
@@ -234,16 +287,20 @@ __global__ __launch_bounds__(256) void k_align2(const Align2Args A)
     } else {
         a = a_report = A.anchor_in[pair];
     }
+    if (!HASN) {
+        // an 'N' can only be met if the haplotype has one or the slice reaches the 'N' padding
+        const bool need_n = A.hap_has_n[h] != 0 || a + len1 + 1 > hl;
+        if (__any(need_n)) {
+            if (lane == 0) A.n_list[atomicAdd(A.n_count, 1)] = wave;
+            return;
+        }
+    }
     const uint16_t* hx = A.hapx + A.hap_xoff[h] + a;
     const uint16_t* rx = A.readx + A.read_xoff[r];
-    // an 'N' can only be met if the haplotype has one or the slice reaches the 'N' padding
-    const bool need_n = A.hap_has_n[h] != 0 || a + len1 + 1 > hl;
-    u16 best;
-    if (__any(need_n)) best = align_pair<true>(hx, rx, len2, s_tab, (uint32_t)A.ge, (uint32_t)A.np);
-    else               best = align_pair<false>(hx, rx, len2, s_tab, (uint32_t)A.ge, (uint32_t)A.np);
+    const u16 best = align_pair<HASN>(hx, rx, len2, s_tab, (uint32_t)A.ge, (uint32_t)A.np);
 
     if (active) {
-        const int sc = failed ? -1 : (int)best;                  // align.c:234
+        const int sc = failed ? -1 : (int)best;                              // align.c:234
         A.score[pair] = sc;
         A.anchor[pair] = a_report;
         if (A.like) {
@@ -257,6 +314,27 @@ __global__ __launch_bounds__(256) void k_align2(const Align2Args A)
             A.like[pair] = lk;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_align2(const Align2Args A)
+{
+    __shared__ uint8_t s_tab[256];
+    s_tab[threadIdx.x] = A.tab[threadIdx.x];
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256u + threadIdx.x) >> 6));
+    if (wave >= A.n_waves) return;
+    align_wave<false>(A, wave, s_tab);
+}
+
+__global__ __launch_bounds__(256) void k_align2n(const Align2Args A)
+{
+    __shared__ uint8_t s_tab[256];
+    s_tab[threadIdx.x] = A.tab[threadIdx.x];
+    __syncthreads();
+    const int n = *A.n_count;         // written by the previous kernel on this stream
+    const int w0 = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256u + threadIdx.x) >> 6));
+    for (int i = w0; i < n; i += (int)gridDim.x * 4)
+        align_wave<true>(A, A.n_list[i], s_tab);
 }
 
 // ---------------------------------------------------------------------------
