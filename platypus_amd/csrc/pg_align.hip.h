@@ -34,7 +34,16 @@ constexpr uint32_t kPadElem = ('0' << 8) | 64;   // align.c:119-120, packed as (
 // half-rate 32-bit minimum or pick an SGPR operand.
 typedef uint16_t u16;
 __device__ __forceinline__ u16 add16(u16 a, u16 b) { return (u16)(a + b); }
-__device__ __forceinline__ u16 min16(u16 a, u16 b) { return a < b ? a : b; }
+// The empty asm hides the result from the instruction selector, which would
+// otherwise merge two chained minima into v_min3_u16.  That form -- like every
+// SDWA form, which the build switches off -- does not just issue slowly on
+// gfx950: a few of them in a loop of 16-bit VOP2 instructions halve the rate of
+// the whole loop (measured with a replay of this kernel's own instruction stream).
+__device__ __forceinline__ u16 min16(u16 a, u16 b) {
+    u16 r = a < b ? a : b;
+    asm("" : "+v"(r));
+    return r;
+}
 // Hide how a value was made, so that the compiler cannot fold its producer into
 // the consumer as a three-operand instruction (v_bitop3_b16, v_min3_u16: half /
 // quarter rate on gfx950).  Emits nothing.
@@ -138,24 +147,52 @@ __device__ __forceinline__ void dp_iter(Lane2& L, int t, int len2, int e, uint32
     const u16 hrun = min16((u16)(he & 0x00ffu), in_vgpr((uint32_t)(room > 0 ? room : 0)));
     const u16 gnew = s_tab[hrun];
 
+    // The half-steps are written as stages of eight independent instructions with
+    // a scheduling barrier between stages.  On gfx950 a VALU instruction that
+    // reads a result still in flight stalls its wavefront for about nine cycles
+    // (two issue slots); with every dependent pair a whole stage apart no such
+    // stall occurs and two wavefronts per SIMD keep the VALU busy.
+#define PG_STAGE() __builtin_amdgcn_sched_barrier(0)
     // ---- even half-step, align.c:129-173 ----
     if (EDGE && t >= len2) L.best = take_min<0>(L.best, L.m1g, t - len2, C.Ps);   // align.c:134-156
-    u16 m1[8], i1[8], u1[8], d1n[8], m2g[8];
+    u16 x[8], y[8], m1[8], i1[8], u1[8], d1n[8], m2g[8];
+    PG_STAGE();
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        u16 c = min16((u16)(L.s2[(J - k) & 7] ^ L.s1[(J + k) & 7]), L.q[(J - k) & 7]);
-        if (HASN) c = min16(opaque(c), L.nq[(J + k) & 7]);
-        m1[k] = add16(L.m1g[k], c);
-        i1[k] = min16(L.i2[k], add16(L.m2[k], L.gM[(J + 7 - k) & 7]));
-        if (k == 0) i1[k] = opaque(i1[k]);       // its only reader is the next line
-        u1[k] = min16(m1[k], i1[k]);
+    for (int k = 0; k < 8; ++k) x[k] = (u16)(L.s2[(J - k) & 7] ^ L.s1[(J + k) & 7]);
+    PG_STAGE();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) y[k] = add16(L.m2[k], L.gM[(J + 7 - k) & 7]);
+    PG_STAGE();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = min16(x[k], L.q[(J - k) & 7]);
+    PG_STAGE();
+    if (HASN) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = min16(x[k], L.nq[(J + k) & 7]);
+        PG_STAGE();
     }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) i1[k] = min16(L.i2[k], y[k]);
+    PG_STAGE();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m1[k] = add16(L.m1g[k], x[k]);
+    PG_STAGE();
+#pragma unroll
+    for (int k = 1; k < 8; ++k) x[k] = add16(L.d2[k - 1], C.geP);
+    PG_STAGE();
+#pragma unroll
+    for (int k = 1; k < 8; ++k) y[k] = add16(L.u2[k - 1], L.gP[(J + 8 - k) & 7]);
+    PG_STAGE();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) u1[k] = min16(m1[k], i1[k]);
+    PG_STAGE();
     d1n[0] = C.inf;                   // align.c:168
 #pragma unroll
-    for (int k = 1; k < 8; ++k)
-        d1n[k] = min16(add16(L.d2[k - 1], C.geP), add16(L.u2[k - 1], L.gP[(J + 8 - k) & 7]));
+    for (int k = 1; k < 8; ++k) d1n[k] = min16(x[k], y[k]);
+    PG_STAGE();
 #pragma unroll
     for (int k = 0; k < 8; ++k) m2g[k] = min16(L.u2[k], L.d2[k]);                // align.c:190
+    PG_STAGE();
 
     // ---- align.c:180-187: haplotype window, N limits and gap-open vector take position t+8 ----
     L.s1[J] = opaque((u16)(he & 0xff00u));
@@ -165,19 +202,44 @@ __device__ __forceinline__ void dp_iter(Lane2& L, int t, int len2, int e, uint32
 
     // ---- odd half-step, align.c:190-231 ----
     if (EDGE && t >= len2) L.best = take_min<1>(L.best, m2g, t - len2, C.Ps);     // align.c:195-217
+    PG_STAGE();
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        u16 c = min16((u16)(L.s2[(J - k) & 7] ^ L.s1[(J + 1 + k) & 7]), L.q[(J - k) & 7]);
-        if (HASN) c = min16(opaque(c), L.nq[(J + 1 + k) & 7]);
-        L.m2[k] = add16(m2g[k], c);
-        L.d2[k] = min16(add16(d1n[k], C.geP), add16(u1[k], L.gP[(J + 8 - k) & 7]));
-        L.m1g[k] = min16(u1[k], d1n[k]);                                          // align.c:129, next iteration
+    for (int k = 0; k < 8; ++k) x[k] = (u16)(L.s2[(J - k) & 7] ^ L.s1[(J + 1 + k) & 7]);
+    PG_STAGE();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) y[k] = add16(d1n[k], C.geP);
+    PG_STAGE();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = min16(x[k], L.q[(J - k) & 7]);
+    PG_STAGE();
+    if (HASN) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = min16(x[k], L.nq[(J + 1 + k) & 7]);
+        PG_STAGE();
     }
 #pragma unroll
-    for (int k = 0; k < 7; ++k) L.i2[k] = min16(i1[k + 1], add16(m1[k + 1], L.gM[(J + 7 - k) & 7]));
+    for (int k = 0; k < 8; ++k) L.d2[k] = add16(u1[k], L.gP[(J + 8 - k) & 7]);
+    PG_STAGE();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) L.m2[k] = add16(m2g[k], x[k]);
+    PG_STAGE();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) L.d2[k] = min16(y[k], L.d2[k]);
+    PG_STAGE();
+#pragma unroll
+    for (int k = 0; k < 7; ++k) x[k] = add16(m1[k + 1], L.gM[(J + 7 - k) & 7]);
+    PG_STAGE();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) L.m1g[k] = min16(u1[k], d1n[k]);                  // align.c:129, next iteration
+    PG_STAGE();
+#pragma unroll
+    for (int k = 0; k < 7; ++k) L.i2[k] = min16(i1[k + 1], x[k]);
     L.i2[7] = C.inf15;                // align.c:230
+    PG_STAGE();
 #pragma unroll
     for (int k = 0; k < 8; ++k) L.u2[k] = min16(L.m2[k], L.i2[k]);
+    PG_STAGE();
+#undef PG_STAGE
 }
 
 __device__ __forceinline__ uint32_t elem4(const uint2& b, int j) {   // element j (0..3) of four packed u16

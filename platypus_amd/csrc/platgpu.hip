@@ -50,6 +50,7 @@ struct pg_ctx {
     std::string table;
     DevBuf<int16_t> d_tab4;
     DevBuf<uint8_t> d_tab1;              // table[h] - 33
+    int lds_pad = 0;                     // PG_ALIGN_LDS_PAD: extra LDS per workgroup, to lower occupancy in experiments
     int align_kernel = 2;                // PG_ALIGN_KERNEL=1 selects the packed-int16 kernel (A/B runs)
     DevBuf<double> d_exp_score, d_exp_mapq;
 
@@ -172,6 +173,7 @@ int pg_ctx_create(int device_ordinal, int max_read_len, pg_ctx** out) {
     c->device = device_ordinal;
     c->max_read_len = max_read_len;
     c->table = kDefaultTable;
+    if (const char* k = std::getenv("PG_ALIGN_LDS_PAD")) c->lds_pad = std::atoi(k);
     if (const char* k = std::getenv("PG_ALIGN_KERNEL")) c->align_kernel = std::atoi(k) == 1 ? 1 : 2;
     if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
         delete c;
@@ -483,12 +485,14 @@ int pg_align_launch(pg_ctx* c) {
     B.score = c->d_score.p; B.anchor = c->d_anchor.p; B.like = c->d_like.p;
     B.n_count = c->d_n_list.p; B.n_list = c->d_n_list.p + 1;
     B.n_waves = c->n_waves; B.ge = c->gapextend; B.np = c->nucprior;
+    if (c->lds_pad > 0)
+        PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_align2), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_pad));
     PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_ALIGN], c->stream));
     if (c->align_kernel == 1)
         hipLaunchKernelGGL(pg::k_align, dim3((c->n_waves + 3) / 4), dim3(256), 0, c->stream, A);
     else {
         PG_HIP(c, hipMemsetAsync(c->d_n_list.p, 0, 256, c->stream));
-        hipLaunchKernelGGL(pg::k_align2, dim3((c->n_waves + 3) / 4), dim3(256), 0, c->stream, B);
+        hipLaunchKernelGGL(pg::k_align2, dim3((c->n_waves + 3) / 4), dim3(256), c->lds_pad, c->stream, B);
         PG_HIP(c, hipGetLastError());
         hipLaunchKernelGGL(pg::k_align2n, dim3(std::min((c->n_waves + 3) / 4, 2048)), dim3(256), 0, c->stream, B);
     }

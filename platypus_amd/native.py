@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libplatgpu.so")
+# PLATGPU_LIB points at another build of the same library (A/B timing of kernel variants)
+LIB_PATH = os.environ.get("PLATGPU_LIB") or os.path.join(_HERE, "lib", "libplatgpu.so")
 
 PG_OK = 0
 PG_ERR_NO_DEVICE, PG_ERR_INVALID, PG_ERR_HIP, PG_ERR_UNSUPPORTED, PG_ERR_STATE = -1, -2, -3, -4, -5
