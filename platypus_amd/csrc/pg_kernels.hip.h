@@ -208,6 +208,228 @@ __global__ __launch_bounds__(256) void k_vote(const uint8_t* __restrict__ hap,
 }
 
 // ---------------------------------------------------------------------------
+// 2-bit packing of bases for the 7-mer hash: code(p) of platypus/calign.pyx:89-94
+// sits at bits [2(p%16), 2(p%16)+2) of word p/16.  Row w of sequence s starts at
+// word off2[s]; rows end with two zero words, so the 64-bit window of any 7-mer
+// start can be read without a bounds test.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack_codes(const uint8_t* __restrict__ seq,
+                                                    const int64_t* __restrict__ soff,
+                                                    const int64_t* __restrict__ off2,
+                                                    uint32_t* __restrict__ dst, int n_seq)
+{
+    const int wave = (int)((blockIdx.x * 256u + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+    const int n_waves = (int)(gridDim.x * 4u);
+    for (int s = wave; s < n_seq; s += n_waves) {
+        const int64_t s0 = soff[s];
+        const int len = (int)(soff[s + 1] - s0);
+        const int64_t d0 = off2[s];
+        const int nw = (int)(off2[s + 1] - d0);
+        for (int w = lane; w < nw; w += 64) {
+            uint32_t bits = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int p = w * 16 + j;
+                if (p < len) bits |= nuc_code(seq[s0 + p]) << (2 * j);
+            }
+            dst[d0 + w] = bits;
+        }
+    }
+}
+
+// the 14 bits of the 7-mer starting at base i of a packed row: a relabelling of
+// the hash of platypus/calign.pyx:81-96 (first base in the low bits instead of
+// the high ones), used for both the table and the look-ups
+__device__ __forceinline__ uint32_t hash7_packed(const uint32_t* __restrict__ row, int i) {
+    const uint32_t w0 = row[i >> 4], w1 = row[(i >> 4) + 1];
+    const unsigned long long v = ((unsigned long long)w1 << 32) | w0;
+    return (uint32_t)(v >> (2 * (i & 15))) & 0x3fffu;
+}
+
+struct VoteRec {      // one (read, indel haplotype) pair of k_vote2, built on the host
+    int32_t pair;     // index into the pair list
+    int32_t rlen;     // read length
+    int64_t r2off;    // word offset of the read's packed row
+};
+
+// ---------------------------------------------------------------------------
+// k_vote2: one workgroup per indel-bearing haplotype, blockDim.x / 64 reads in
+// flight.  The unique-7-mer table of platypus/calign.pyx:99-123 is built once
+// per haplotype in LDS (16384 x u16: 0 absent, i+1 unique start, 0xffff
+// repeated) instead of once per read.  A wavefront maps one read at a time
+// (platypus/calign.pyx:126-158) in three sweeps over its votes, none of which
+// depends on the order in which lanes reach LDS:
+//   A  atomic +1 on the vote counter of every hit position
+//   B  maximum final count
+//   C  backwards over the votes: a position holding the maximum is met first at
+//      its LAST vote -- the vote that brought it to the maximum; the reference's
+//      winner, the first position to reach the final maximum, is therefore the
+//      one met last.  Counters are cleared on the way.
+// The kernel is latency bound (a few reads per haplotype), so each wavefront
+// fetches its first read before the table is built, keeps the packed read in a
+// private LDS row for the three sweeps, and fetches the next read meanwhile.
+// LDS: table (32 KiB) | per wavefront: counters u16[cnt_stride] | packed read u32[row_words].
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t hash7_lds(const uint32_t* row, int i) {
+    const uint32_t w0 = row[i >> 4], w1 = row[(i >> 4) + 1];
+    return __builtin_amdgcn_alignbit(w1, w0, 2 * (i & 15)) & 0x3fffu;
+}
+
+// The three sweeps for one read.  KEEP: the read has at most 4 x 64 votes and
+// their positions stay in registers between the sweeps; otherwise every sweep
+// looks its votes up again.
+template <bool KEEP>
+__device__ __forceinline__ int vote_read(const uint16_t* tab, const uint32_t* row, uint16_t* cnt16,
+                                         uint32_t* cnt32, int rl, int nv, int n_chunks, int lane)
+{
+    // vote of read offset i: position pos (calign.pyx:144-147) and counter slot idx
+    auto vote = [&](int i, int& pos, int& idx) -> bool {
+        pos = 0; idx = 0;
+        if (i >= nv) return false;
+        const int pv = (int16_t)tab[hash7_lds(row, i)];
+        pos = pv - 1 - i;
+        idx = pos + rl;
+        return pv > 0;
+    };
+    int kpos[4], kidx[4];
+    bool kval[4];
+    if (KEEP) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) kval[c] = c < n_chunks && vote(c * 64 + lane, kpos[c], kidx[c]);
+    }
+    // A: count.  Most votes of a chunk name the same position: the lanes that agree with
+    // the chunk's first vote are added as one number, only the others go one by one.
+    auto sweep_a = [&](bool valid, int pos, int idx) {
+        const unsigned long long any = __ballot(valid);
+        if (any) {
+            const int lead = __ffsll((long long)any) - 1;
+            const int p0 = __builtin_amdgcn_readlane(pos, lead);
+            const bool same = valid && pos == p0;
+            const unsigned long long m = __ballot(same);
+            if (lane == lead) atomicAdd(&cnt32[idx >> 1], (uint32_t)__popcll(m) << ((idx & 1) * 16));
+            if (valid && !same) atomicAdd(&cnt32[idx >> 1], 1u << ((idx & 1) * 16));
+        }
+    };
+    if (KEEP) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (c < n_chunks) sweep_a(kval[c], kpos[c], kidx[c]);
+    } else {
+        for (int c = 0; c < n_chunks; ++c) {
+            int pos, idx;
+            const bool v = vote(c * 64 + lane, pos, idx);
+            sweep_a(v, pos, idx);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // B: maximum final count
+    int cmax = 0;
+    if (KEEP) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < n_chunks && kval[c]) cmax = max(cmax, (int)cnt16[kidx[c]]);
+    } else {
+        for (int c = 0; c < n_chunks; ++c) {
+            int pos, idx;
+            if (vote(c * 64 + lane, pos, idx)) cmax = max(cmax, (int)cnt16[idx]);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cmax = max(cmax, __shfl_xor(cmax, off));
+    // C: backwards; the position met last among those at the maximum wins
+    int winner = 0;                              // calign.pyx:137
+    auto sweep_c = [&](bool valid, int pos, int idx) {
+        const bool at_max = valid && (int)cnt16[idx] == cmax;
+        unsigned long long mask = __ballot(at_max);
+        while (mask) {
+            const int top = 63 - __clzll((long long)mask);
+            winner = __builtin_amdgcn_readlane(pos, top);
+            const bool same = at_max && pos == winner;
+            if (same) cnt16[idx] = 0;            // earlier votes of this position no longer show the maximum
+            mask &= ~__ballot(same);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (valid) cnt16[idx] = 0;
+        __builtin_amdgcn_wave_barrier();
+    };
+    if (KEEP) {
+#pragma unroll
+        for (int c = 3; c >= 0; --c) if (c < n_chunks) sweep_c(kval[c], kpos[c], kidx[c]);
+    } else {
+        for (int c = n_chunks - 1; c >= 0; --c) {
+            int pos, idx;
+            const bool valid = vote(c * 64 + lane, pos, idx);
+            sweep_c(valid, pos, idx);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    return winner;
+}
+
+__global__ __launch_bounds__(1024) void k_vote2(const uint32_t* __restrict__ hap2,
+                                                const int64_t* __restrict__ hap2off,
+                                                const int32_t* __restrict__ hap_len,
+                                                const uint32_t* __restrict__ read2,
+                                                const int32_t* __restrict__ vh_list,
+                                                const int64_t* __restrict__ vh_ptr,
+                                                const VoteRec* __restrict__ vh_recs,
+                                                int32_t* __restrict__ anchor, int cnt_stride, int row_words)
+{
+    extern __shared__ uint32_t lds[];
+    uint16_t* tab = reinterpret_cast<uint16_t*>(lds);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_thr = blockDim.x, n_wav = n_thr >> 6;
+    uint16_t* cnt16 = tab + kHashSize + wave * cnt_stride;
+    uint32_t* cnt32 = reinterpret_cast<uint32_t*>(cnt16);
+    uint32_t* row = lds + (kHashSize + n_wav * cnt_stride) / 2 + wave * row_words;
+    const int h = vh_list[blockIdx.x];
+    const uint32_t* hw = hap2 + hap2off[h];
+    const int L = hap_len[h];
+    const int64_t q_end = vh_ptr[blockIdx.x + 1];
+    int64_t q = vh_ptr[blockIdx.x] + wave;
+
+    // first read of this wavefront: in flight while the table is built
+    VoteRec rec = {0, 0, 0};
+    uint32_t w_first = 0;
+    if (q < q_end) {
+        rec = vh_recs[q];
+        if (lane < (rec.rlen + 15) / 16 + 1) w_first = read2[rec.r2off + lane];
+    }
+
+    const int total_dw = (kHashSize + n_wav * cnt_stride) / 2;
+    for (int i = tid; i < total_dw; i += n_thr) lds[i] = 0;
+    __syncthreads();
+    const int nk = L - kHashNucs;               // last 7-mer is left out, calign.pyx:114
+    for (int i = tid; i < nk; i += n_thr) tab[hash7_packed(hw, i)] = (uint16_t)(i + 1);
+    __syncthreads();
+    for (int i = tid; i < nk; i += n_thr) {
+        const uint32_t k = hash7_packed(hw, i);
+        if (tab[k] != (uint16_t)(i + 1)) tab[k] = 0xffffu;   // some other start owns the slot: repeated
+    }
+    __syncthreads();
+
+    while (q < q_end) {
+        const int pair = rec.pair, rl = rec.rlen;
+        const int n_words = (rl + 15) / 16 + 1;
+        // packed read into the wavefront's LDS row
+        if (lane < n_words) row[lane] = w_first;
+        for (int w = 64 + lane; w < n_words; w += 64) row[w] = read2[rec.r2off + w];
+        __builtin_amdgcn_wave_barrier();
+        // next read on its way
+        q += n_wav;
+        if (q < q_end) {
+            rec = vh_recs[q];
+            if (lane < (rec.rlen + 15) / 16 + 1) w_first = read2[rec.r2off + lane];
+        }
+        const int nv = rl - kHashNucs;          // calign.pyx:143
+        const int n_chunks = nv > 0 ? (nv + 63) >> 6 : 0;
+        int winner;
+        if (n_chunks <= 4) winner = vote_read<true>(tab, row, cnt16, cnt32, rl, nv, n_chunks, lane);
+        else               winner = vote_read<false>(tab, row, cnt16, cnt32, rl, nv, n_chunks, lane);
+        if (lane == 0) anchor[pair] = winner - 8 > 0 ? winner - 8 : 0;   // calign.pyx:67
+    }
+}
+
+// ---------------------------------------------------------------------------
 // k_align
 // ---------------------------------------------------------------------------
 struct AlignArgs {

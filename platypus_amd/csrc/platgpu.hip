@@ -50,6 +50,7 @@ struct pg_ctx {
     std::string table;
     DevBuf<int16_t> d_tab4;
     DevBuf<uint8_t> d_tab1;              // table[h] - 33
+    int vote_waves = 8;                  // PG_VOTE_WAVES: wavefronts per workgroup of the vote kernel (experiments)
     int lds_pad = 0;                     // PG_ALIGN_LDS_PAD: extra LDS per workgroup, to lower occupancy in experiments
     int align_kernel = 2;                // PG_ALIGN_KERNEL=1 selects the packed-int16 kernel (A/B runs)
     DevBuf<double> d_exp_score, d_exp_mapq;
@@ -61,6 +62,8 @@ struct pg_ctx {
     std::vector<int32_t> h_hap_varlen;
     DevBuf<uint8_t> d_hap_raw, d_hap, d_run, d_hap_has_n;
     DevBuf<uint16_t> d_hapx;
+    DevBuf<uint32_t> d_hap2;            // 2-bit packed bases
+    DevBuf<int64_t> d_hap2off;
     DevBuf<int64_t> d_hap_soff, d_hap_doff;
     DevBuf<int32_t> d_hap_len, d_hap_start, d_hap_varlen;
 
@@ -68,10 +71,11 @@ struct pg_ctx {
     int n_reads = 0;
     int max_rlen = 0;
     bool uniform_rlen = true;
-    std::vector<int64_t> h_read_off;
+    std::vector<int64_t> h_read_off, h_read2off;
     DevBuf<uint8_t> d_rseq, d_rqual;
     DevBuf<uint16_t> d_readx;
-    DevBuf<int64_t> d_roff, d_read_xoff;
+    DevBuf<int64_t> d_roff, d_read_xoff, d_read2off;
+    DevBuf<uint32_t> d_read2;           // 2-bit packed bases
     DevBuf<int32_t> d_read_pos, d_read_mapq;
 
     // pairs
@@ -82,6 +86,7 @@ struct pg_ctx {
     DevBuf<int32_t> d_pair_hap, d_pair_read, d_order, d_vh_list, d_vh_pairs, d_anchor_in, d_n_list;
     DevBuf<int64_t> d_vh_ptr;
     DevBuf<pg::WaveDesc> d_waves;
+    DevBuf<pg::VoteRec> d_vh_recs;
 
     // results
     bool launched = false;
@@ -173,6 +178,7 @@ int pg_ctx_create(int device_ordinal, int max_read_len, pg_ctx** out) {
     c->device = device_ordinal;
     c->max_read_len = max_read_len;
     c->table = kDefaultTable;
+    if (const char* k = std::getenv("PG_VOTE_WAVES")) c->vote_waves = std::max(1, std::min(16, std::atoi(k)));
     if (const char* k = std::getenv("PG_ALIGN_LDS_PAD")) c->lds_pad = std::atoi(k);
     if (const char* k = std::getenv("PG_ALIGN_KERNEL")) c->align_kernel = std::atoi(k) == 1 ? 1 : 2;
     if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
@@ -192,7 +198,8 @@ int pg_ctx_destroy(pg_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     c->d_tab4.release(); c->d_tab1.release(); c->d_hap_has_n.release(); c->d_hapx.release();
-    c->d_readx.release(); c->d_read_xoff.release();
+    c->d_readx.release(); c->d_read_xoff.release(); c->d_hap2.release(); c->d_hap2off.release();
+    c->d_read2.release(); c->d_read2off.release();
     c->d_exp_score.release(); c->d_exp_mapq.release();
     c->d_hap_raw.release(); c->d_hap.release(); c->d_run.release();
     c->d_hap_soff.release(); c->d_hap_doff.release();
@@ -201,7 +208,7 @@ int pg_ctx_destroy(pg_ctx* c) {
     c->d_read_pos.release(); c->d_read_mapq.release();
     c->d_pair_hap.release(); c->d_pair_read.release(); c->d_order.release();
     c->d_vh_list.release(); c->d_vh_pairs.release(); c->d_anchor_in.release(); c->d_vh_ptr.release();
-    c->d_n_list.release(); c->d_waves.release(); c->d_score.release(); c->d_anchor.release(); c->d_like.release();
+    c->d_n_list.release(); c->d_vh_recs.release(); c->d_waves.release(); c->d_score.release(); c->d_anchor.release(); c->d_like.release();
     c->d_g1.release(); c->d_g2.release(); c->d_gn.release(); c->d_gout.release();
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -280,6 +287,15 @@ int pg_haps_upload(pg_ctx* c, int n, const char* seq, const int64_t* off,
     hipLaunchKernelGGL(pg::k_pack_hapx, dim3(grid), dim3(256), 0, c->stream, c->d_hap_raw.p, c->d_hap_soff.p,
                        c->d_hap_doff.p, c->d_hapx.p, c->d_hap_has_n.p, n, pad, cap);
     PG_HIP(c, hipGetLastError());
+    std::vector<int64_t> off2(n + 1);
+    off2[0] = 0;
+    for (int i = 0; i < n; ++i) off2[i + 1] = off2[i] + (len[i] + 15) / 16 + 2;
+    PG_HIP(c, c->d_hap2.reserve((size_t)off2[n] + 16));
+    PG_HIP(c, c->d_hap2off.reserve(n + 1));
+    PG_HIP(c, hipMemcpyAsync(c->d_hap2off.p, off2.data(), (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(pg::k_pack_codes, dim3(std::min((n + 3) / 4, 65536)), dim3(256), 0, c->stream, c->d_hap_raw.p,
+                       c->d_hap_soff.p, c->d_hap2off.p, c->d_hap2.p, n);
+    PG_HIP(c, hipGetLastError());
     PG_HIP(c, hipStreamSynchronize(c->stream));   // host vectors above go out of scope
     c->h_hap_off.assign(soff.begin(), soff.end());
     c->h_hap_varlen.assign(var_seq_len, var_seq_len + n);
@@ -333,8 +349,18 @@ int pg_reads_upload(pg_ctx* c, int n, const char* seq, const char* qual, const i
     hipLaunchKernelGGL(pg::k_pack_readx, dim3(std::min((n + 3) / 4, 65536)), dim3(256), 0, c->stream, c->d_rseq.p,
                        c->d_rqual.p, c->d_roff.p, c->d_read_xoff.p, c->d_readx.p, n);
     PG_HIP(c, hipGetLastError());
+    std::vector<int64_t> off2(n + 1);
+    off2[0] = 0;
+    for (int i = 0; i < n; ++i) off2[i + 1] = off2[i] + (roff[i + 1] - roff[i] + 15) / 16 + 2;
+    PG_HIP(c, c->d_read2.reserve((size_t)off2[n] + 16));
+    PG_HIP(c, c->d_read2off.reserve(n + 1));
+    PG_HIP(c, hipMemcpyAsync(c->d_read2off.p, off2.data(), (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(pg::k_pack_codes, dim3(std::min((n + 3) / 4, 65536)), dim3(256), 0, c->stream, c->d_rseq.p,
+                       c->d_roff.p, c->d_read2off.p, c->d_read2.p, n);
+    PG_HIP(c, hipGetLastError());
     PG_HIP(c, hipStreamSynchronize(c->stream));
     c->h_read_off.swap(roff);
+    c->h_read2off.swap(off2);
     c->max_rlen = maxl;
     c->uniform_rlen = (maxl == minl);
     c->n_reads = n;
@@ -382,6 +408,7 @@ int pg_pairs_upload(pg_ctx* c, int64_t np, const int32_t* hap_idx, const int32_t
 
     // ---- pairs on indel-bearing haplotypes, grouped by haplotype ---------------
     std::vector<int32_t> vh_list, vh_pairs;
+    std::vector<pg::VoteRec> vh_recs;
     std::vector<int64_t> vh_ptr;
     {
         std::vector<int64_t> per_hap(c->n_haps + 1, 0);
@@ -395,6 +422,11 @@ int pg_pairs_upload(pg_ctx* c, int64_t np, const int32_t* hap_idx, const int32_t
             std::vector<int64_t> cur(start.begin(), start.end() - 1);
             for (int64_t p = 0; p < np; ++p)
                 if (c->h_hap_varlen[hap_idx[p]] != 0) vh_pairs[cur[hap_idx[p]]++] = (int32_t)p;
+            vh_recs.resize(nv);
+            for (int64_t i = 0; i < nv; ++i) {
+                const int r = read_idx[vh_pairs[i]];
+                vh_recs[i] = {vh_pairs[i], (int32_t)(c->h_read_off[r + 1] - c->h_read_off[r]), c->h_read2off[r]};
+            }
             for (int h = 0; h < c->n_haps; ++h)
                 if (start[h + 1] > start[h]) { vh_list.push_back(h); vh_ptr.push_back(start[h]); }
             vh_ptr.push_back(nv);
@@ -424,6 +456,8 @@ int pg_pairs_upload(pg_ctx* c, int64_t np, const int32_t* hap_idx, const int32_t
         PG_HIP(c, hipMemcpyAsync(c->d_vh_list.p, vh_list.data(), vh_list.size() * 4, hipMemcpyHostToDevice, c->stream));
         PG_HIP(c, hipMemcpyAsync(c->d_vh_ptr.p, vh_ptr.data(), vh_ptr.size() * 8, hipMemcpyHostToDevice, c->stream));
         PG_HIP(c, hipMemcpyAsync(c->d_vh_pairs.p, vh_pairs.data(), vh_pairs.size() * 4, hipMemcpyHostToDevice, c->stream));
+        PG_HIP(c, c->d_vh_recs.reserve(vh_recs.size()));
+        PG_HIP(c, hipMemcpyAsync(c->d_vh_recs.p, vh_recs.data(), vh_recs.size() * sizeof(pg::VoteRec), hipMemcpyHostToDevice, c->stream));
     }
     PG_HIP(c, hipStreamSynchronize(c->stream));
     c->n_waves = (int)waves.size();
@@ -451,13 +485,18 @@ int pg_align_launch(pg_ctx* c) {
     if (c->n_vote_haps > 0) {
         int cnt_stride = c->max_hap_len + c->max_rlen + 8;
         cnt_stride += cnt_stride & 1;
-        const size_t lds = (size_t)pg::kHashSize * 2 + (size_t)4 * cnt_stride * 2;
+        // as many reads in flight per haplotype as LDS allows, two workgroups per CU if possible
+        const int row_words = (c->max_rlen + 15) / 16 + 2;
+        int n_wav = c->vote_waves;
+        auto lds_bytes = [&](int w) { return (size_t)pg::kHashSize * 2 + (size_t)w * (cnt_stride * 2 + row_words * 4); };
+        while (n_wav > 1 && lds_bytes(n_wav) > 160 * 1024) n_wav >>= 1;
+        const size_t lds = lds_bytes(n_wav);
         if (lds > 160 * 1024)
             return fail(c, PG_ERR_UNSUPPORTED, "vote counters for haplotype length %d need %zu bytes of LDS", c->max_hap_len, lds);
-        PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_vote), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(pg::k_vote, dim3(c->n_vote_haps), dim3(256), lds, c->stream, c->d_hap.p, c->d_hap_doff.p,
-                           c->d_hap_len.p, c->d_rseq.p, c->d_roff.p, c->d_vh_list.p, c->d_vh_ptr.p, c->d_vh_pairs.p,
-                           c->d_pair_read.p, c->d_anchor_in.p, cnt_stride);
+        PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_vote2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(pg::k_vote2, dim3(c->n_vote_haps), dim3(64 * n_wav), lds, c->stream, c->d_hap2.p,
+                           c->d_hap2off.p, c->d_hap_len.p, c->d_read2.p, c->d_vh_list.p, c->d_vh_ptr.p,
+                           c->d_vh_recs.p, c->d_anchor_in.p, cnt_stride, row_words);
         PG_HIP(c, hipGetLastError());
     }
     PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_ANCHOR + 1], c->stream));
