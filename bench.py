@@ -40,9 +40,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from platypus_amd import shard
+    rank, world, local_rank = shard.rank_info()
     import torch
     dist = None
     if world > 1:
@@ -89,9 +88,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=sync_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = shard.max_over_ranks(dt, dist, sync_dev)      # the only cross-rank operation of the run
 
     cells_per_pair = 16 * (L + 8)
     total_cells = float(n_pairs) * cells_per_pair * world * args.steps
@@ -119,6 +116,9 @@ def main():
         "kernel_gcups": float(n_pairs) * cells_per_pair / k_avg / 1e9,
         "hbm_algorithmic_gbps": float(n_pairs) * (2 * L + 24) / k_avg / 1e9,
         "hbm_peak_gbps": 8000.0,
+        # share of the VALU issue rate: executed VALU instructions (173 per DP iteration, 64 lanes;
+        # count from the shipped ISA and PMC SQ_INSTS_VALU) over 128 lanes/clk/CU x 256 CUs x 2.36 GHz
+        "issue_frac": (float(n_pairs) / 64 * (L + 8) * 173 * 64 / k_avg) / (128 * 256 * 2.36e9),
         "traffic": None,
     }
 

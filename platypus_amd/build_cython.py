@@ -1,0 +1,56 @@
+"""Build the Cython 3 layer (calign, cwindow, chaplotype, cgenotype) in-tree.
+
+    python -m platypus_amd.build_cython [--force]
+
+The extension modules link against lib/libplatgpu.so (rpath $ORIGIN/lib).
+"""
+import os
+import subprocess
+import sys
+import sysconfig
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+MODULES = ["calign", "cwindow", "chaplotype", "cgenotype"]
+PXD = ["samtoolsWrapper.pxd", "platgpu.pxd", "calign.pxd", "cwindow.pxd", "chaplotype.pxd", "cgenotype.pxd"]
+
+
+def _ext_path(mod):
+    return os.path.join(HERE, mod + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def _stale(mod):
+    out = _ext_path(mod)
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    deps = [os.path.join(HERE, mod + ".pyx")] + [os.path.join(HERE, p) for p in PXD]
+    deps.append(os.path.join(ROOT, "include", "platgpu.h"))
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force=False, verbose=True):
+    from Cython.Build import cythonize  # noqa: F401  (fails early if Cython is missing)
+    import numpy as np
+    inc = [sysconfig.get_paths()["include"], np.get_include(), os.path.join(ROOT, "include")]
+    build_dir = os.path.join(HERE, "_cybuild")
+    os.makedirs(build_dir, exist_ok=True)
+    for mod in MODULES:
+        if not force and not _stale(mod):
+            continue
+        c_file = os.path.join(build_dir, mod + ".c")
+        cmd = [sys.executable, "-m", "cython", "-3", "-I", ROOT, "-o", c_file, os.path.join(HERE, mod + ".pyx")]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd, cwd=ROOT)
+        cc = ["gcc", "-O2", "-fPIC", "-shared", "-fno-strict-aliasing", "-Wno-unused-function",
+              "-DNPY_NO_DEPRECATED_API=NPY_1_7_API_VERSION"] + ["-I" + i for i in inc] + \
+             ["-o", _ext_path(mod), c_file, "-L" + os.path.join(HERE, "lib"), "-lplatgpu",
+              "-Wl,-rpath,$ORIGIN/lib", "-lm"]
+        if verbose:
+            print(" ".join(cc), flush=True)
+        subprocess.check_call(cc)
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,165 @@
+# cython: language_level=3, boundscheck=False, wraparound=False, cdivision=True
+"""Haplotype with the reference's alignReads interface, scored on the GPU.
+
+Mirrors the part of platypus/chaplotype.pyx the alignment path uses: the
+fields alignNoTraceback is fed from (cHaplotypeSequence, startPos, hapLen,
+varSeqLen, cHomopolQ -- chaplotype.pyx:50-86), ``alignReads`` with its
+per-individual cache (chaplotype.pyx:239-270) and the cache's life time
+(chaplotype.pyx:88-100).  The mutated sequence is handed in ready-made: building
+it from variants (chaplotype.pyx:283-353) belongs to the caller.
+
+``prefetchWindow`` is the batch hook: called once at the top of Caller.setup
+(cpopulation.pyx:658), it scores every haplotype of the window against every
+individual's window reads in a single launch and fills all caches, so the
+per-(genotype, individual) loop of cpopulation.pyx:698-725 only hits caches.
+"""
+import math
+
+import numpy as np
+
+from libc.stdlib cimport malloc, free
+from libc.string cimport memcpy
+
+from platypus_amd.samtoolsWrapper cimport cAlignedRead
+from platypus_amd.calign cimport alignBatch
+from platypus_amd.cwindow cimport bamReadBuffer
+
+# platypus/chaplotype.pyx:37-38 (the literal at :40 is the same string)
+cdef list per_base_indel_errors = [2.9e-5, 2.9e-5, 2.9e-5, 2.9e-5, 4.3e-5, 1.1e-4, 2.4e-4, 5.7e-4, 1.0e-3, 1.4e-3] + \
+    [1.4e-3 + 4.3e-4 * (n - 10) for n in range(11, 50)]
+cdef bytes homopolq = bytes([int(33.5 + 10 * math.log((idx + 1) * q) / math.log(0.1))
+                             for idx, q in enumerate(per_base_indel_errors)])
+
+
+cdef class Haplotype:
+    def __init__(self, bytes refName, int startPos, int endPos, bytes haplotypeSequence,
+                 int varSeqLen, tuple variants=()):
+        """startPos/endPos are the padded bounds of chaplotype.pyx:70-71, varSeqLen the
+        sum of |nAdded - nRemoved| over the variants (chaplotype.pyx:66-68)."""
+        self.refName = refName
+        self.startPos = startPos
+        self.endPos = endPos
+        self.variants = variants
+        self.varSeqLen = varSeqLen
+        self.haplotypeSequence = haplotypeSequence
+        self.cHaplotypeSequence = self.haplotypeSequence
+        self.hapLen = <int>len(haplotypeSequence)
+        self.hash = -1
+        self.cHomopolQ = homopolq
+        self.likesByIndCache = NULL
+        self.lenCache = 0
+
+    def __dealloc__(self):
+        cdef int index
+        if self.lenCache > 0:
+            for index in range(self.lenCache):
+                if self.likesByIndCache[index] != NULL:
+                    free(self.likesByIndCache[index])
+            free(self.likesByIndCache)
+
+    def __hash__(self):
+        if self.hash == -1:
+            self.hash = hash((self.refName, self.startPos, self.endPos, self.haplotypeSequence))
+        return self.hash
+
+    def __eq__(self, other):
+        cdef Haplotype o
+        if not isinstance(other, Haplotype):
+            return False
+        o = other
+        return self.refName == o.refName and self.startPos == o.startPos and \
+            self.haplotypeSequence == o.haplotypeSequence
+
+    cdef int ensureCache(self, int nIndividuals) except -1:
+        cdef int i
+        if self.lenCache == 0:
+            self.likesByIndCache = <double**>malloc(nIndividuals * sizeof(double*))
+            self.lenCache = nIndividuals
+            for i in range(nIndividuals):
+                self.likesByIndCache[i] = NULL
+        return 0
+
+    cdef double* alignReads(self, int individualIndex, cAlignedRead** start, cAlignedRead** end,
+                            int nReads, int nIndividuals) except NULL:
+        """platypus/chaplotype.pyx:239-270 with the read loop replaced by one launch."""
+        cdef int hs = self.startPos, vl = self.varSeqLen, hl = self.hapLen
+        cdef char* seq = self.cHaplotypeSequence
+        self.ensureCache(nIndividuals)
+        if self.likesByIndCache[individualIndex] == NULL:
+            self.likesByIndCache[individualIndex] = <double*>malloc((nReads if nReads > 0 else 1) * sizeof(double))
+            if nReads > 0:
+                alignBatch(1, &seq, &hs, &vl, &hl, start, end, self.cHomopolQ, 3, 2,
+                           self.likesByIndCache[individualIndex], NULL, NULL)
+        return self.likesByIndCache[individualIndex]
+
+    # ---- Python-visible helpers ----
+    def alignReadsPy(self, int individualIndex, bamReadBuffer buf, int nIndividuals):
+        cdef int n = <int>(buf.windowEnd - buf.windowStart)
+        cdef double* p = self.alignReads(individualIndex, buf.windowStart, buf.windowEnd, n, nIndividuals)
+        cdef double[::1] out = np.empty(n, dtype=np.float64)
+        if n > 0:
+            memcpy(&out[0], p, n * sizeof(double))
+        return np.asarray(out)
+
+    def isCached(self, int individualIndex):
+        return self.lenCache > individualIndex and self.likesByIndCache[individualIndex] != NULL
+
+    property sequence:
+        def __get__(self):
+            return self.haplotypeSequence
+
+
+cdef int prefetchWindowC(list haplotypes, list readBuffers) except -1:
+    """Score all haplotypes x all individuals' window reads in one launch and fill
+    every likesByIndCache entry that is still empty."""
+    cdef int nH = len(haplotypes), nI = len(readBuffers)
+    cdef int h, i, r, nTot = 0, n
+    cdef Haplotype hap
+    cdef bamReadBuffer buf
+    if nH == 0 or nI == 0:
+        return 0
+    for i in range(nI):
+        buf = readBuffers[i]
+        nTot += <int>(buf.windowEnd - buf.windowStart)
+    cdef cAlignedRead** reads = <cAlignedRead**>malloc((nTot + 1) * sizeof(cAlignedRead*))
+    cdef char** seqs = <char**>malloc(nH * sizeof(char*))
+    cdef int* starts = <int*>malloc(nH * sizeof(int))
+    cdef int* vls = <int*>malloc(nH * sizeof(int))
+    cdef int* lens = <int*>malloc(nH * sizeof(int))
+    cdef double* like = <double*>malloc((<size_t>nH * nTot + 1) * sizeof(double))
+    cdef int base = 0
+    try:
+        for i in range(nI):
+            buf = readBuffers[i]
+            n = <int>(buf.windowEnd - buf.windowStart)
+            for r in range(n):
+                reads[base + r] = buf.windowStart[r]
+            base += n
+        for h in range(nH):
+            hap = haplotypes[h]
+            seqs[h] = hap.cHaplotypeSequence
+            starts[h] = hap.startPos
+            vls[h] = hap.varSeqLen
+            lens[h] = hap.hapLen
+        if nTot > 0:
+            hap = haplotypes[0]
+            alignBatch(nH, seqs, starts, vls, lens, reads, reads + nTot, hap.cHomopolQ, 3, 2, like, NULL, NULL)
+        for h in range(nH):
+            hap = haplotypes[h]
+            hap.ensureCache(nI)
+            base = 0
+            for i in range(nI):
+                buf = readBuffers[i]
+                n = <int>(buf.windowEnd - buf.windowStart)
+                if hap.likesByIndCache[i] == NULL:
+                    hap.likesByIndCache[i] = <double*>malloc((n if n > 0 else 1) * sizeof(double))
+                    if n > 0:
+                        memcpy(hap.likesByIndCache[i], like + <size_t>h * nTot + base, n * sizeof(double))
+                base += n
+    finally:
+        free(reads); free(seqs); free(starts); free(vls); free(lens); free(like)
+    return 0
+
+
+def prefetchWindow(list haplotypes, list readBuffers):
+    prefetchWindowC(haplotypes, readBuffers)

@@ -1,0 +1,24 @@
+# C ABI of libplatgpu.so (include/platgpu.h)
+from libc.stdint cimport int32_t, int64_t
+
+cdef extern from "platgpu.h":
+    ctypedef struct pg_ctx:
+        pass
+    enum:
+        PG_OK
+        PG_SCORE_ASSERT_FAILED
+    int pg_ctx_create(int device_ordinal, int max_read_len, pg_ctx** out)
+    int pg_ctx_destroy(pg_ctx* ctx)
+    const char* pg_last_error_string(const pg_ctx* ctx)
+    int pg_set_params(pg_ctx* ctx, int gapextend, int nucprior, const char* table, int table_len)
+    int pg_haps_upload(pg_ctx* ctx, int n, const char* seq, const int64_t* offsets,
+                       const int32_t* start_pos, const int32_t* var_seq_len)
+    int pg_reads_upload(pg_ctx* ctx, int n, const char* seq, const char* qual, const int64_t* offsets,
+                        const int32_t* pos, const int32_t* mapq)
+    int pg_pairs_upload(pg_ctx* ctx, int64_t n_pairs, const int32_t* hap_idx, const int32_t* read_idx)
+    int pg_pairs_block(pg_ctx* ctx, int hap_lo, int hap_hi, int read_lo, int read_hi)
+    int pg_align_launch(pg_ctx* ctx)
+    int pg_sync(pg_ctx* ctx)
+    int pg_results_fetch(pg_ctx* ctx, int32_t* score, int32_t* anchor, double* likelihood)
+    int pg_genotype_loglik(pg_ctx* ctx, int64_t n_gen, const int64_t* pair_base1, const int64_t* pair_base2,
+                           const int32_t* n_reads, double* out)

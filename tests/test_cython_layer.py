@@ -1,0 +1,96 @@
+"""The Cython 3 mirror of the reference's calign / cwindow / chaplotype /
+cgenotype interfaces.  Window pointers are host logic (CPU test); everything
+that aligns runs on the GPU and is compared with the CPU checker."""
+import numpy as np
+import pytest
+
+
+def _buffers(b, H, R):
+    """One bamReadBuffer per window of a synthetic batch (reads sorted by pos)."""
+    from platypus_amd import cwindow
+    bufs = []
+    W = len(b["hap_off"]) // H if False else b["meta"]["windows"]
+    for w in range(W):
+        lo, hi = w * R, (w + 1) * R
+        order = np.argsort(b["read_pos"][lo:hi], kind="stable") + lo
+        seq = np.concatenate([b["read_seq"][b["read_off"][r]:b["read_off"][r + 1]] for r in order])
+        qual = np.concatenate([b["read_qual"][b["read_off"][r]:b["read_off"][r + 1]] for r in order])
+        lens = (b["read_off"][order + 1] - b["read_off"][order])
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        pos = b["read_pos"][order]
+        bufs.append((order, cwindow.bamReadBuffer(b"chr20", int(pos.min()), int(pos.max()) + 1000, seq, qual, off,
+                                                  pos, (pos + lens).astype(np.int32), b["read_mapq"][order])))
+    return bufs
+
+
+def test_window_pointers_match_reference_rule():
+    """setWindowPointers against a direct restatement of cwindow.pyx:242-267."""
+    from platypus_amd import cwindow
+    rng = np.random.default_rng(5)
+    n = 400
+    pos = np.sort(rng.integers(1000, 6000, n)).astype(np.int32)
+    lens = rng.integers(30, 151, n)
+    end = (pos + lens + rng.integers(-5, 30, n)).astype(np.int32)      # deletions / soft clips move the end
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    seq = np.full(off[-1], 65, np.uint8)
+    buf = cwindow.bamReadBuffer(b"1", 1000, 7000, seq, seq, off, pos, end, np.full(n, 60, np.int32))
+    longest = int((end - pos).max())
+    for _ in range(300):
+        s = int(rng.integers(900, 6100)); e = s + int(rng.integers(1, 400))
+        lo = int(np.searchsorted(pos, max(1, s - longest), side="left"))
+        hi = int(np.searchsorted(pos, e, side="left"))
+        while lo < n and end[lo] <= s:
+            lo += 1
+        assert buf.setWindow(s, e) == (lo, min(hi, n))
+    empty = cwindow.bamReadBuffer(b"1", 0, 10, np.zeros(0, np.uint8), np.zeros(0, np.uint8), np.zeros(1, np.int64),
+                                  np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.int32))
+    assert empty.setWindow(5, 9) == (0, 0)
+
+
+@pytest.mark.gpu
+def test_haplotype_align_reads_prefetch_and_genotypes():
+    from oracle import pyoracle as po
+    from platypus_amd import calign, cgenotype, chaplotype, synth
+    H, R = 4, 30
+    b = synth.make_batch(n_windows=5, haps_per_window=H, reads_per_window=R, read_len=100, hap_len=520,
+                         indel_hap_frac=0.5, seed=77)
+    exp_s, exp_a = po.run_pairs(synth.oracle_view(b), reuse_hash=True)
+    mq = b["read_mapq"]
+    for w, (order, buf) in enumerate(_buffers(b, H, R)):
+        haps = []
+        for h in range(w * H, (w + 1) * H):
+            seq = b["hap_seq"][b["hap_off"][h]:b["hap_off"][h + 1]].tobytes()
+            haps.append(chaplotype.Haplotype(b"chr20", int(b["hap_start"][h]), int(b["hap_start"][h]) + len(seq),
+                                             seq, int(b["hap_varlen"][h])))
+        buf.setWindow(int(b["hap_start"][w * H]) + 200, int(b["hap_start"][w * H]) + 320)
+        lo, hi = buf.windowRange()
+        sel = order[lo:hi]                                  # original read ids inside the window
+        def expected(h):
+            return np.array([po.likelihood(exp_s[h * R + (r - w * R)], mq[r]) for r in sel])
+        # (1) the reference's call pattern: one haplotype, one individual, cache on second call
+        first = haps[0].alignReadsPy(0, buf, 1)
+        assert np.array_equal(first, expected(w * H)) and haps[0].isCached(0)
+        assert np.array_equal(haps[0].alignReadsPy(0, buf, 1), first)
+        # (2) the batch hook fills every other cache in one launch
+        chaplotype.prefetchWindow(haps, [buf])
+        for k, hp in enumerate(haps):
+            assert hp.isCached(0)
+            assert np.array_equal(hp.alignReadsPy(0, buf, 1), expected(w * H + k))
+        # (3) genotype log-likelihoods: same arithmetic and order as cgenotype.pyx:58-61
+        gts = cgenotype.allGenotypes(haps)
+        assert len(gts) == H * (H + 1) // 2
+        ll = cgenotype.genotypeLogLikelihoods(haps, gts, [buf])
+        g = 0
+        for i in range(H):
+            for j in range(i, H):
+                assert ll[0, g] == po.genotype_loglik(expected(w * H + i), expected(w * H + j))
+                g += 1
+    # single-pair entry point with the reference's signature
+    h, r = 1, 3
+    got = calign.alignNoTracebackPy(b["read_seq"][b["read_off"][r]:b["read_off"][r + 1]].tobytes(),
+                                    b["read_qual"][b["read_off"][r]:b["read_off"][r + 1]].tobytes(),
+                                    int(b["read_pos"][r]), int(mq[r]),
+                                    b["hap_seq"][b["hap_off"][h]:b["hap_off"][h + 1]].tobytes(),
+                                    int(b["hap_start"][h]), int(b["hap_varlen"][h]), po.HOMOPOLQ)
+    assert got == po.likelihood(exp_s[h * R + r], mq[r])
+    calign.closeDevice()
