@@ -47,15 +47,25 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        try:
-            dist.init_process_group("nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
-            sync_dev = torch.device("cuda", local_rank)
-        except Exception:                                     # control plane only: gloo will do
+        # one rank per GPU; on a box with fewer GPUs than ranks (rehearsals) ranks share devices
+        device = local_rank % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(device)
+        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")   # the process group only carries a barrier and one MAX
+        if backend == "nccl":
+            try:
+                dist.init_process_group("nccl", rank=rank, world_size=world,
+                                        device_id=torch.device("cuda", device))
+                sync_dev = torch.device("cuda", device)
+                dist.barrier()
+            except Exception:                                 # control plane only: gloo will do
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                backend = "gloo"
+        if backend != "nccl":
             dist.init_process_group("gloo", rank=rank, world_size=world)
             sync_dev = torch.device("cpu")
     else:
+        device = 0
         torch.cuda.set_device(0)
 
     from platypus_amd import native, synth
@@ -64,7 +74,7 @@ def main():
                              read_len=L, hap_len=750, indel_hap_frac=0.25,
                              seed=synth.SEED + rank)
     n_pairs = len(batch["pair_hap"])
-    ctx = native.AlignContext(local_rank if world > 1 else 0)
+    ctx = native.AlignContext(device)
     ctx.upload_batch(batch)                                    # inputs resident in HBM from here on
 
     def barrier():
