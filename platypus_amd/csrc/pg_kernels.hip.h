@@ -275,6 +275,17 @@ __device__ __forceinline__ uint32_t hash7_lds(const uint32_t* row, int i) {
     return __builtin_amdgcn_alignbit(w1, w0, 2 * (i & 15)) & 0x3fffu;
 }
 
+// maximum of non-negative values over the 64 lanes, in registers (DPP), result in every lane
+__device__ __forceinline__ int wave_max_nonneg(int v) {
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true));   // row_shr:1
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true));   // row_shr:2
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true));   // row_shr:4
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true));   // row_shr:8
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true));   // row_bcast:15
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true));   // row_bcast:31
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 // The three sweeps for one read.  KEEP: the read has at most 4 x 64 votes and
 // their positions stay in registers between the sweeps; otherwise every sweep
 // looks its votes up again.
@@ -296,6 +307,34 @@ __device__ __forceinline__ int vote_read(const uint16_t* tab, const uint32_t* ro
     if (KEEP) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) kval[c] = c < n_chunks && vote(c * 64 + lane, kpos[c], kidx[c]);
+    }
+    if (KEEP) {
+        // Shortcut without counters: a position named by more than half of all votes is the
+        // only one that can hold the maximum, so it wins whatever the order of the votes.
+        // Tried for the positions of the first and of the last vote of the read.
+        unsigned long long vm[4];
+        int total = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { vm[c] = __ballot(kval[c]); total += __popcll(vm[c]); }
+        if (total == 0) return 0;                // calign.pyx:137: nothing votes
+        int cf = 0, cl = 0;
+#pragma unroll
+        for (int c = 3; c >= 0; --c) if (vm[c]) cf = c;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (vm[c]) cl = c;
+        const unsigned long long mf = cf == 0 ? vm[0] : cf == 1 ? vm[1] : cf == 2 ? vm[2] : vm[3];
+        const unsigned long long ml = cl == 0 ? vm[0] : cl == 1 ? vm[1] : cl == 2 ? vm[2] : vm[3];
+        const int lf = __ffsll((long long)mf) - 1, ll = 63 - __clzll((long long)ml);
+        const int posf = cf == 0 ? kpos[0] : cf == 1 ? kpos[1] : cf == 2 ? kpos[2] : kpos[3];
+        const int posl = cl == 0 ? kpos[0] : cl == 1 ? kpos[1] : cl == 2 ? kpos[2] : kpos[3];
+        const int cand[2] = {__builtin_amdgcn_readlane(posf, lf), __builtin_amdgcn_readlane(posl, ll)};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            int n = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) n += __popcll(__ballot(kval[c] && kpos[c] == cand[k]));
+            if (2 * n > total) return cand[k];
+        }
     }
     // A: count.  Most votes of a chunk name the same position: the lanes that agree with
     // the chunk's first vote are added as one number, only the others go one by one.
@@ -333,8 +372,7 @@ __device__ __forceinline__ int vote_read(const uint16_t* tab, const uint32_t* ro
             if (vote(c * 64 + lane, pos, idx)) cmax = max(cmax, (int)cnt16[idx]);
         }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) cmax = max(cmax, __shfl_xor(cmax, off));
+    cmax = wave_max_nonneg(cmax);
     // C: backwards; the position met last among those at the maximum wins
     int winner = 0;                              // calign.pyx:137
     auto sweep_c = [&](bool valid, int pos, int idx) {
@@ -387,12 +425,30 @@ __global__ __launch_bounds__(1024) void k_vote2(const uint32_t* __restrict__ hap
     const int64_t q_end = vh_ptr[blockIdx.x + 1];
     int64_t q = vh_ptr[blockIdx.x] + wave;
 
-    // first read of this wavefront: in flight while the table is built
-    VoteRec rec = {0, 0, 0};
-    uint32_t w_first = 0;
-    if (q < q_end) {
-        rec = vh_recs[q];
-        if (lane < (rec.rlen + 15) / 16 + 1) w_first = read2[rec.r2off + lane];
+    // This wavefront's reads are q, q + n_wav, ...  Lane j fetches the record of the j-th of
+    // them (64 per batch), and the packed rows of the next four reads are always in flight:
+    // the loop below never waits for a record -> row chain of two dependent global loads.
+    const int64_t n_mine = q < q_end ? (q_end - q + n_wav - 1) / n_wav : 0;
+    VoteRec lrec = {0, 0, 0};
+    if (lane < n_mine) lrec = vh_recs[q + (int64_t)lane * n_wav];
+    uint32_t wf[4] = {0, 0, 0, 0};
+    auto rec_of = [&](int j, int& pair, int& rl, int64_t& r2) {
+        pair = __builtin_amdgcn_readlane(lrec.pair, j);
+        rl = __builtin_amdgcn_readlane(lrec.rlen, j);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)lrec.r2off, j);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)lrec.r2off >> 32), j);
+        r2 = (int64_t)(((uint64_t)hi << 32) | lo);
+    };
+    auto fetch_row = [&](int j, int nb) -> uint32_t {
+        if (j >= nb) return 0;
+        int pair, rl; int64_t r2;
+        rec_of(j, pair, rl, r2);
+        return lane < (rl + 15) / 16 + 1 ? read2[r2 + lane] : 0u;
+    };
+    {
+        const int nb0 = n_mine < 64 ? (int)n_mine : 64;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wf[k] = fetch_row(k, nb0);
     }
 
     const int total_dw = (kHashSize + n_wav * cnt_stride) / 2;
@@ -407,25 +463,36 @@ __global__ __launch_bounds__(1024) void k_vote2(const uint32_t* __restrict__ hap
     }
     __syncthreads();
 
-    while (q < q_end) {
-        const int pair = rec.pair, rl = rec.rlen;
-        const int n_words = (rl + 15) / 16 + 1;
-        // packed read into the wavefront's LDS row
-        if (lane < n_words) row[lane] = w_first;
-        for (int w = 64 + lane; w < n_words; w += 64) row[w] = read2[rec.r2off + w];
-        __builtin_amdgcn_wave_barrier();
-        // next read on its way
-        q += n_wav;
-        if (q < q_end) {
-            rec = vh_recs[q];
-            if (lane < (rec.rlen + 15) / 16 + 1) w_first = read2[rec.r2off + lane];
+    for (int64_t b0 = 0; b0 < n_mine; b0 += 64) {
+        const int nb = n_mine - b0 < 64 ? (int)(n_mine - b0) : 64;
+        if (b0 > 0) {                            // next batch of records and its first four rows
+            lrec = lane < nb ? vh_recs[q + (b0 + lane) * n_wav] : VoteRec{0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wf[k] = fetch_row(k, nb);
         }
-        const int nv = rl - kHashNucs;          // calign.pyx:143
-        const int n_chunks = nv > 0 ? (nv + 63) >> 6 : 0;
-        int winner;
-        if (n_chunks <= 4) winner = vote_read<true>(tab, row, cnt16, cnt32, rl, nv, n_chunks, lane);
-        else               winner = vote_read<false>(tab, row, cnt16, cnt32, rl, nv, n_chunks, lane);
-        if (lane == 0) anchor[pair] = winner - 8 > 0 ? winner - 8 : 0;   // calign.pyx:67
+        for (int j0 = 0; j0 < nb; j0 += 4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int j = j0 + k;
+                if (j < nb) {
+                    int pair, rl; int64_t r2;
+                    rec_of(j, pair, rl, r2);
+                    const int n_words = (rl + 15) / 16 + 1;
+                    // packed read into the wavefront's LDS row
+                    if (lane < n_words) row[lane] = wf[k];
+                    for (int w = 64 + lane; w < n_words; w += 64) row[w] = read2[r2 + w];
+                    __builtin_amdgcn_wave_barrier();
+                    wf[k] = fetch_row(j + 4, nb);    // the read four places on
+                    const int nv = rl - kHashNucs;   // calign.pyx:143
+                    const int n_chunks = nv > 0 ? (nv + 63) >> 6 : 0;
+                    int winner;
+                    if (n_chunks <= 4) winner = vote_read<true>(tab, row, cnt16, cnt32, rl, nv, n_chunks, lane);
+                    else               winner = vote_read<false>(tab, row, cnt16, cnt32, rl, nv, n_chunks, lane);
+                    if (lane == 0) anchor[pair] = winner - 8 > 0 ? winner - 8 : 0;   // calign.pyx:67
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
     }
 }
 
