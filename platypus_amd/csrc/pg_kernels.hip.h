@@ -1,14 +1,9 @@
-// Device kernels of libplatgpu (gfx950 only).
+// Device kernels of libplatgpu (gfx950 only), all but the banded DP (pg_align.hip.h).
 //
-//   k_pack_haps   per-haplotype upload pass: padded device copy + run-length array
-//   k_vote        7-mer anchoring (hash_sequence + map_read of the reference)
-//   k_align       banded affine-gap DP, one lane per (haplotype, read) pair
+//   k_pack_codes  upload pass: 2-bit packed bases of haplotypes and reads
+//   k_vote2       7-mer anchoring (hash_sequence + map_read of the reference)
 //   k_genotype    per-genotype log-likelihood sums
-//
-// The DP keeps the reference's arithmetic exactly: 16-bit wrapping adds,
-// signed 16-bit minima, every cost scaled by 4 (platypus/c/align.c:28-31).
-// A lane owns one pair; the reference's 8-lane int16 vectors become four
-// VGPRs of two packed int16 each and are worked on with v_pk_* instructions.
+//   k_pk_rate     issue-rate probe of the packed int16 VALU instructions
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -39,174 +34,12 @@ __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) {
 __device__ __forceinline__ uint32_t pk_min_i(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
 }
-__device__ __forceinline__ uint32_t pk_min_u(uint32_t a, uint32_t b) {
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
-}
-__device__ __forceinline__ uint32_t pk_mul(uint32_t a, uint32_t b) {
-    return __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, a) * __builtin_bit_cast(u16x2, b)));
-}
-// {hi.lo16 : lo.hi16}: the 64-bit value hi:lo shifted right by 16
-__device__ __forceinline__ uint32_t align16(uint32_t hi, uint32_t lo) {
-    return __builtin_amdgcn_alignbit(hi, lo, 16);
-}
-
-// v[] holds int16 lanes 0..7 (lane 2r in the low half of v[r]).
-// Move every lane one place up and put `ins` (low 16 bits) into lane 0.
-__device__ __forceinline__ void shift_up(uint32_t (&v)[4], uint32_t ins) {
-    v[3] = align16(v[3], v[2]);
-    v[2] = align16(v[2], v[1]);
-    v[1] = align16(v[1], v[0]);
-    v[0] = (v[0] << 16) | (ins & 0xffffu);
-}
-// Move every lane one place down and put `ins` into lane 7.
-__device__ __forceinline__ void shift_down(uint32_t (&v)[4], uint32_t ins) {
-    v[0] = align16(v[1], v[0]);
-    v[1] = align16(v[2], v[1]);
-    v[2] = align16(v[3], v[2]);
-    v[3] = (v[3] >> 16) | (ins << 16);
-}
-
-// ---------------------------------------------------------------------------
-// k_pack_haps: device layout of the haplotypes.
-// Haplotype h occupies dst[doff[h] .. doff[h]+len+pad): its bases followed by
-// `pad` 'N's -- the extension platypus/calign.pyx:73-75 appends when a voted
-// anchor leaves fewer than readLen+15 bases.  run[] holds, per position, the
-// number of following equal bases (an 'N' never extends a run), capped at
-// `cap` = table length - 1: the homopolymer count platypus/c/align.c:73-90
-// derives per call, before its truncation at the slice end.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pack_haps(const uint8_t* __restrict__ src,
-                                                   const int64_t* __restrict__ soff,
-                                                   const int64_t* __restrict__ doff,
-                                                   uint8_t* __restrict__ dst, uint8_t* __restrict__ run,
-                                                   int n_haps, int pad, int cap)
-{
-    for (int h = blockIdx.x; h < n_haps; h += gridDim.x) {
-        const int64_t s0 = soff[h];
-        const int len = (int)(soff[h + 1] - s0);
-        const int64_t d0 = doff[h];
-        for (int p = threadIdx.x; p < len + pad; p += blockDim.x) {
-            uint8_t c = 'N';
-            int r = 0;
-            if (p < len) {
-                c = src[s0 + p];
-                if (c != 'N') {
-                    while (r < cap && p + r + 1 < len && src[s0 + p + r + 1] == c) ++r;
-                }
-            }
-            dst[d0 + p] = c;
-            run[d0 + p] = (uint8_t)r;
-        }
-    }
-}
-
 // 7-mer code of platypus/calign.pyx:81-96: per base c = ch & 7, 7 -> 2, two low bits kept.
 __device__ __forceinline__ uint32_t nuc_code(uint32_t ch) {
     uint32_t c = ch & 7u;
     c = (c == 7u) ? 2u : c;
     return c & 3u;
 }
-__device__ __forceinline__ uint32_t hash7(const uint8_t* s) {
-    uint32_t h = 0;
-#pragma unroll
-    for (int j = 0; j < kHashNucs; ++j) h = (h << 2) + nuc_code(s[j]);
-    return h;
-}
-
-// ---------------------------------------------------------------------------
-// k_vote: one workgroup per indel-bearing haplotype.
-// The unique-7-mer table of platypus/calign.pyx:99-123 is built once per
-// haplotype in LDS (16384 x int16: 0 absent, i+1 unique start, 0xffff
-// repeated) instead of once per read; each wavefront then maps one read at a
-// time as platypus/calign.pyx:126-158 does: votes are cast in read order, the
-// first position whose running count reaches the final maximum wins.
-// LDS: table (32 KiB) + per-wave vote counters u16[cnt_stride].
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_vote(const uint8_t* __restrict__ hap,
-                                              const int64_t* __restrict__ hap_doff,
-                                              const int32_t* __restrict__ hap_len,
-                                              const uint8_t* __restrict__ rseq,
-                                              const int64_t* __restrict__ roff,
-                                              const int32_t* __restrict__ vh_list,
-                                              const int64_t* __restrict__ vh_ptr,
-                                              const int32_t* __restrict__ vh_pairs,
-                                              const int32_t* __restrict__ pair_read,
-                                              int32_t* __restrict__ anchor, int cnt_stride)
-{
-    extern __shared__ uint32_t lds[];
-    uint16_t* tab = reinterpret_cast<uint16_t*>(lds);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint16_t* cnt = tab + kHashSize + wave * cnt_stride;
-    const int h = vh_list[blockIdx.x];
-    const uint8_t* hs = hap + hap_doff[h];
-    const int L = hap_len[h];
-
-    const int total_dw = (kHashSize + 4 * cnt_stride) / 2;
-    for (int i = tid; i < total_dw; i += 256) lds[i] = 0;
-    __syncthreads();
-    const int nk = L - kHashNucs;               // last 7-mer is left out, calign.pyx:114
-    for (int i = tid; i < nk; i += 256) tab[hash7(hs + i)] = (uint16_t)(i + 1);
-    __syncthreads();
-    for (int i = tid; i < nk; i += 256) {
-        const uint32_t k = hash7(hs + i);
-        if (tab[k] != (uint16_t)(i + 1)) tab[k] = 0xffffu;   // some other start owns the slot: repeated
-    }
-    __syncthreads();
-
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
-    for (int64_t q = vh_ptr[blockIdx.x] + wave; q < vh_ptr[blockIdx.x + 1]; q += 4) {
-        const int pair = vh_pairs[q];
-        const int r = pair_read[pair];
-        const int64_t r0 = roff[r];
-        const int rl = (int)(roff[r + 1] - r0);
-        const uint8_t* rs = rseq + r0;
-        const int nv = rl - kHashNucs;          // calign.pyx:143
-        int best_rank = 0, best_i = 0, best_pos = 0;
-        for (int c0 = 0; c0 < nv; c0 += 64) {
-            const int i = c0 + lane;
-            bool valid = i < nv;
-            int pos = 0, idx = 0, old = 0;
-            if (valid) {
-                const int pv = (int16_t)tab[hash7(rs + i)];
-                valid = pv > 0;
-                pos = pv - 1 - i;
-                idx = pos + rl;
-                if (valid) old = cnt[idx];
-            }
-            // running count of each vote, in read order, for lanes that share a position
-            uint64_t rem = __ballot(valid);
-            int rank = 0;
-            while (rem) {
-                const int leader = __ffsll((unsigned long long)rem) - 1;
-                const int pl = __shfl(pos, leader);
-                const bool same = valid && pos == pl;
-                const uint64_t m = __ballot(same);
-                if (same) rank = old + __popcll(m & lt_mask) + 1;
-                if (lane == leader) cnt[idx] = (uint16_t)(old + __popcll(m));
-                rem &= ~m;
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (valid && rank > best_rank) { best_rank = rank; best_i = i; best_pos = pos; }
-        }
-        // highest running count; among equals the earliest vote (smallest i)
-        unsigned long long key = ((unsigned long long)(uint32_t)best_rank << 32) | (uint32_t)(0x7fffffff - best_i);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const unsigned long long o = __shfl_xor(key, off);
-            key = o > key ? o : key;
-        }
-        const unsigned long long mine = ((unsigned long long)(uint32_t)best_rank << 32) | (uint32_t)(0x7fffffff - best_i);
-        const uint64_t win = __ballot(mine == key && best_rank > 0);
-        int maxpos = 0;
-        if (win) maxpos = __shfl(best_pos, __ffsll((unsigned long long)win) - 1);
-        if (lane == 0) anchor[pair] = maxpos - 8 > 0 ? maxpos - 8 : 0;   // calign.pyx:67
-        // clear this read's counters
-        uint32_t* c32 = reinterpret_cast<uint32_t*>(cnt);
-        for (int x = lane; x < (L + rl) / 2 + 1; x += 64) c32[x] = 0;
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
 // ---------------------------------------------------------------------------
 // 2-bit packing of bases for the 7-mer hash: code(p) of platypus/calign.pyx:89-94
 // sits at bits [2(p%16), 2(p%16)+2) of word p/16.  Row w of sequence s starts at
@@ -492,194 +325,6 @@ __global__ __launch_bounds__(1024) void k_vote2(const uint32_t* __restrict__ hap
                     __builtin_amdgcn_wave_barrier();
                 }
             }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// k_align
-// ---------------------------------------------------------------------------
-struct AlignArgs {
-    const uint8_t* hap;        // padded haplotypes
-    const uint8_t* run;        // run-length array, same indexing
-    const int64_t* hap_doff;
-    const int32_t* hap_len;
-    const int32_t* hap_start;
-    const int32_t* hap_varlen;
-    const uint8_t* rseq;
-    const uint8_t* rqual;
-    const int64_t* roff;
-    const int32_t* read_pos;
-    const int32_t* read_mapq;
-    const int32_t* pair_hap;
-    const int32_t* pair_read;
-    const int32_t* order;      // slot -> pair (NULL: identity)
-    const WaveDesc* waves;
-    const int32_t* anchor_in;  // voted anchors (pairs on indel haplotypes)
-    const int16_t* tab4;       // 4*(table[h]-33), 256 entries
-    const double* exp_score;   // exp(mLTOT*s), s = 0..2048, host libm
-    const double* exp_mapq;    // exp(mLTOT*q), q = 0..255, host libm
-    int32_t* score;
-    int32_t* anchor;
-    double* like;
-    int n_waves;
-    int ge4, np4;              // 4*gapextend, 4*nucprior
-};
-
-struct DpState {
-    uint32_t m1[4], i1[4], d1[4], m2[4], i2[4], d2[4];   // align.c:37-42
-    uint32_t s1[4], nq[4], s2[4], q2[4], go[4];          // align.c:44-47,100
-};
-
-// One iteration of the loop at platypus/c/align.c:106-232 for the lane's pair.
-// EDGE iterations carry the start-up mask (t < 8, align.c:127-128,189) and the
-// score pick-up (t >= len2, align.c:134-156,195-217); the others do neither.
-template <bool EDGE>
-__device__ __forceinline__ void dp_step(DpState& st, int t, int len2, uint32_t c2, uint32_t q4,
-                                        uint32_t c1, uint32_t nqv, uint32_t gnew,
-                                        uint32_t ge2, uint32_t np2, int& best)
-{
-    shift_up(st.s2, c2);
-    shift_up(st.q2, q4);
-    if (EDGE && t < 8) {
-        const uint32_t keep = (t & 1) ? 0x0000ffffu : 0xffff0000u;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (r == (t >> 1)) { st.m1[r] &= keep; st.m2[r] &= keep; }
-    }
-    // ---- even half-step ----
-#pragma unroll
-    for (int r = 0; r < 4; ++r) st.m1[r] = pk_min_i(st.m1[r], pk_min_i(st.i1[r], st.d1[r]));
-    if (EDGE && t >= len2) {
-        const int j = t - len2;
-        uint32_t w = 0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) if (r == (j >> 1)) w = st.m1[r];
-        const int sc = (int)(int16_t)((j & 1) ? (w >> 16) : (w & 0xffffu));
-        best = sc < best ? sc : best;
-    }
-    uint32_t dn[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const uint32_t neq = pk_min_u(st.s2[r] ^ st.s1[r], 0x00010001u);
-        const uint32_t cost = pk_min_i(pk_mul(neq, st.q2[r]), st.nq[r]);
-        st.m1[r] = pk_add(st.m1[r], cost);
-        dn[r] = pk_min_i(pk_add(st.d2[r], ge2), pk_add(pk_min_i(st.m2[r], st.i2[r]), st.go[r]));
-        st.i1[r] = pk_add(pk_min_i(pk_add(st.i2[r], ge2), pk_add(st.m2[r], st.go[r])), np2);
-    }
-    shift_up(dn, kPosInf);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) st.d1[r] = dn[r];
-    // ---- haplotype window, N limits, gap-open vector ----
-    shift_down(st.s1, c1);
-    shift_down(st.nq, nqv);
-    shift_up(st.go, gnew);
-    // ---- odd half-step ----
-#pragma unroll
-    for (int r = 0; r < 4; ++r) st.m2[r] = pk_min_i(st.m2[r], pk_min_i(st.i2[r], st.d2[r]));
-    if (EDGE && t >= len2) {
-        const int j = t - len2;
-        uint32_t w = 0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) if (r == (j >> 1)) w = st.m2[r];
-        const int sc = (int)(int16_t)((j & 1) ? (w >> 16) : (w & 0xffffu));
-        best = sc < best ? sc : best;
-    }
-    uint32_t in[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const uint32_t neq = pk_min_u(st.s2[r] ^ st.s1[r], 0x00010001u);
-        const uint32_t cost = pk_min_i(pk_mul(neq, st.q2[r]), st.nq[r]);
-        st.m2[r] = pk_add(st.m2[r], cost);
-        st.d2[r] = pk_min_i(pk_add(st.d1[r], ge2), pk_add(pk_min_i(st.m1[r], st.i1[r]), st.go[r]));
-        in[r] = pk_add(pk_min_i(pk_add(st.i1[r], ge2), pk_add(st.m1[r], st.go[r])), np2);
-    }
-    shift_down(in, kPosInf);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) st.i2[r] = in[r];
-}
-
-__global__ __launch_bounds__(256) void k_align(const AlignArgs A)
-{
-    __shared__ int16_t s_tab[256];
-    s_tab[threadIdx.x] = A.tab4[threadIdx.x];
-    __syncthreads();
-
-    const int wave = (int)((blockIdx.x * 256u + threadIdx.x) >> 6);
-    if (wave >= A.n_waves) return;
-    const int lane = threadIdx.x & 63;
-    const WaveDesc wd = A.waves[wave];
-    const bool active = lane < wd.count;
-    const int slot = wd.first + (active ? lane : wd.count - 1);
-    const int pair = A.order ? A.order[slot] : slot;
-    const int h = A.pair_hap[pair], r = A.pair_read[pair];
-    const int len2 = wd.len, len1 = len2 + 15, e = len1 - 1;
-    const int hl = A.hap_len[h];
-
-    // anchor: platypus/calign.pyx:60-67
-    int a, a_report;
-    bool failed = false;
-    if (A.hap_varlen[h] == 0) {
-        const long long hp = (long long)A.read_pos[r] - (long long)A.hap_start[h];
-        const long long a64 = hp - 8 > 0 ? hp - 8 : 0;
-        failed = a64 + len1 > hl;                     // assertion at calign.pyx:61
-        a_report = (int)a64;
-        a = failed ? 0 : a_report;                    // a failed pair still runs, on a slice that exists
-    } else {
-        a = a_report = A.anchor_in[pair];
-    }
-    const uint8_t* hs = A.hap + A.hap_doff[h] + a;
-    const uint8_t* hr = A.run + A.hap_doff[h] + a;
-    const uint8_t* rs = A.rseq + A.roff[r];
-    const uint8_t* rq = A.rqual + A.roff[r];
-
-    const uint32_t ge2 = (uint32_t)A.ge4 * 0x00010001u, np2 = (uint32_t)A.np4 * 0x00010001u;
-    DpState st;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        st.m1[k] = st.i1[k] = st.d1[k] = st.m2[k] = st.i2[k] = st.d2[k] = kPosInf2;
-        st.s2[k] = kPosInf2;                      // align.c:64
-        st.q2[k] = 0x01000100u;                   // align.c:65
-        const uint32_t c0 = hs[2 * k], c1 = hs[2 * k + 1];
-        st.s1[k] = c0 | (c1 << 16);               // align.c:63
-        // align.c:68 -- inside the first 8 columns an 'N' gets no discount
-        st.nq[k] = (c0 == 'N' ? 0x2000u : 0x2004u) | ((c1 == 'N' ? 0x2000u : 0x2004u) << 16);
-        const int h0 = min((int)hr[2 * k], e - 2 * k), h1 = min((int)hr[2 * k + 1], e - 2 * k - 1);
-        st.go[k] = (uint32_t)(uint16_t)s_tab[h0] | ((uint32_t)(uint16_t)s_tab[h1] << 16);   // align.c:100
-    }
-    int best = (int)kPosInf;                      // align.c:34
-
-    auto step = [&](int t, auto edge_tag) {
-        constexpr bool EDGE = decltype(edge_tag)::value;
-        uint32_t c2, q4;
-        if (t < len2) { c2 = rs[t]; q4 = 4u * rq[t]; }          // align.c:114-117
-        else          { c2 = '0';   q4 = 256u; }                // align.c:119-120
-        const int x = 8 + t;
-        const uint32_t c1 = (x < len1) ? (uint32_t)hs[x] : (uint32_t)'N';   // align.c:180
-        const uint32_t nqv = (c1 == 'N') ? 4u : kPosInf;                    // align.c:183
-        const int gi = x < len1 ? x : e;                                    // align.c:186
-        const uint32_t gnew = (uint16_t)s_tab[min((int)hr[gi], e - gi)];
-        dp_step<EDGE>(st, t, len2, c2, q4, c1, nqv, gnew, ge2, np2, best);
-    };
-    const int iters = len2 + 8;                   // align.c:106
-    int t = 0;
-    for (; t < 8 && t < iters; ++t) step(t, std::true_type{});
-    for (; t < len2; ++t) step(t, std::false_type{});
-    for (; t < iters; ++t) step(t, std::true_type{});
-
-    if (active) {
-        const int sc = failed ? -1 : (best >> 2);                           // align.c:234
-        A.score[pair] = sc;
-        A.anchor[pair] = a_report;
-        if (A.like) {
-            double lk = 0.0;                      // swallowed assertion: calign.pyx:61
-            if (!failed) {
-                const double pw = A.exp_mapq[A.read_mapq[r]];
-                const double pr = __dsub_rn(1.0, pw);                       // calign.pyx:55-56
-                lk = __dadd_rn(__dmul_rn(A.exp_score[sc], pr), pw);         // calign.pyx:63,78
-                lk = lk < 1.0 ? lk : 1.0;
-            }
-            A.like[pair] = lk;
         }
     }
 }

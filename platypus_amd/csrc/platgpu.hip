@@ -48,11 +48,9 @@ struct pg_ctx {
     // parameters (platypus/chaplotype.pyx:264)
     int gapextend = 3, nucprior = 2;
     std::string table;
-    DevBuf<int16_t> d_tab4;
     DevBuf<uint8_t> d_tab1;              // table[h] - 33
     int vote_waves = 8;                  // PG_VOTE_WAVES: wavefronts per workgroup of the vote kernel (experiments)
     int lds_pad = 0;                     // PG_ALIGN_LDS_PAD: extra LDS per workgroup, to lower occupancy in experiments
-    int align_kernel = 2;                // PG_ALIGN_KERNEL=1 selects the packed-int16 kernel (A/B runs)
     DevBuf<double> d_exp_score, d_exp_mapq;
 
     // haplotypes
@@ -60,7 +58,7 @@ struct pg_ctx {
     int max_hap_len = 0;
     std::vector<int64_t> h_hap_off;      // host offsets (lengths)
     std::vector<int32_t> h_hap_varlen;
-    DevBuf<uint8_t> d_hap_raw, d_hap, d_run, d_hap_has_n;
+    DevBuf<uint8_t> d_hap_raw, d_hap_has_n;
     DevBuf<uint16_t> d_hapx;
     DevBuf<uint32_t> d_hap2;            // 2-bit packed bases
     DevBuf<int64_t> d_hap2off;
@@ -83,7 +81,7 @@ struct pg_ctx {
     int n_waves = 0;
     int n_vote_haps = 0;
     bool have_order = false;
-    DevBuf<int32_t> d_pair_hap, d_pair_read, d_order, d_vh_list, d_vh_pairs, d_anchor_in, d_n_list;
+    DevBuf<int32_t> d_pair_hap, d_pair_read, d_order, d_vh_list, d_anchor_in, d_n_list;
     DevBuf<int64_t> d_vh_ptr;
     DevBuf<pg::WaveDesc> d_waves;
     DevBuf<pg::VoteRec> d_vh_recs;
@@ -121,17 +119,10 @@ int fail(pg_ctx* c, int code, const char* fmt, ...) {
 const char kDefaultTable[] = "NKJHFA=854210/.-,,+**))((('''&&&%%%$$$$#####\"\"\"\"\"";  // chaplotype.pyx:37-40
 
 int upload_params(pg_ctx* c) {
-    int16_t tab4[256];
+    uint8_t tab1[256];                            // gap-open cost per run length, align.c:85 without its factor 4
     const int n = (int)c->table.size();
-    for (int i = 0; i < 256; ++i) {
-        const int ch = (unsigned char)c->table[std::min(i, n - 1)];
-        tab4[i] = (int16_t)(4 * (ch - '!'));      // align.c:85
-    }
-    uint8_t tab1[256];
-    for (int i = 0; i < 256; ++i) tab1[i] = (uint8_t)(tab4[i] / 4);
-    PG_HIP(c, c->d_tab4.reserve(256));
+    for (int i = 0; i < 256; ++i) tab1[i] = (uint8_t)((unsigned char)c->table[std::min(i, n - 1)] - '!');
     PG_HIP(c, c->d_tab1.reserve(256));
-    PG_HIP(c, hipMemcpyAsync(c->d_tab4.p, tab4, sizeof tab4, hipMemcpyHostToDevice, c->stream));
     PG_HIP(c, hipMemcpyAsync(c->d_tab1.p, tab1, sizeof tab1, hipMemcpyHostToDevice, c->stream));
     // likelihood factors with the host C library, so the device result is the
     // same double the reference computes (calign.pyx:17,55,63)
@@ -180,7 +171,6 @@ int pg_ctx_create(int device_ordinal, int max_read_len, pg_ctx** out) {
     c->table = kDefaultTable;
     if (const char* k = std::getenv("PG_VOTE_WAVES")) c->vote_waves = std::max(1, std::min(16, std::atoi(k)));
     if (const char* k = std::getenv("PG_ALIGN_LDS_PAD")) c->lds_pad = std::atoi(k);
-    if (const char* k = std::getenv("PG_ALIGN_KERNEL")) c->align_kernel = std::atoi(k) == 1 ? 1 : 2;
     if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
         delete c;
         return fail(nullptr, PG_ERR_HIP, "cannot create a stream on device %d", device_ordinal);
@@ -197,17 +187,17 @@ int pg_ctx_destroy(pg_ctx* c) {
     if (!c) return PG_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    c->d_tab4.release(); c->d_tab1.release(); c->d_hap_has_n.release(); c->d_hapx.release();
+    c->d_tab1.release(); c->d_hap_has_n.release(); c->d_hapx.release();
     c->d_readx.release(); c->d_read_xoff.release(); c->d_hap2.release(); c->d_hap2off.release();
     c->d_read2.release(); c->d_read2off.release();
     c->d_exp_score.release(); c->d_exp_mapq.release();
-    c->d_hap_raw.release(); c->d_hap.release(); c->d_run.release();
+    c->d_hap_raw.release();
     c->d_hap_soff.release(); c->d_hap_doff.release();
     c->d_hap_len.release(); c->d_hap_start.release(); c->d_hap_varlen.release();
     c->d_rseq.release(); c->d_rqual.release(); c->d_roff.release();
     c->d_read_pos.release(); c->d_read_mapq.release();
     c->d_pair_hap.release(); c->d_pair_read.release(); c->d_order.release();
-    c->d_vh_list.release(); c->d_vh_pairs.release(); c->d_anchor_in.release(); c->d_vh_ptr.release();
+    c->d_vh_list.release(); c->d_anchor_in.release(); c->d_vh_ptr.release();
     c->d_n_list.release(); c->d_vh_recs.release(); c->d_waves.release(); c->d_score.release(); c->d_anchor.release(); c->d_like.release();
     c->d_g1.release(); c->d_g2.release(); c->d_gn.release(); c->d_gout.release();
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -262,8 +252,6 @@ int pg_haps_upload(pg_ctx* c, int n, const char* seq, const int64_t* off,
     const int64_t total = off[n] - off[0];
     doff[n] = total + (int64_t)n * pad;
     PG_HIP(c, c->d_hap_raw.reserve((size_t)total + 16));
-    PG_HIP(c, c->d_hap.reserve((size_t)doff[n] + 64));
-    PG_HIP(c, c->d_run.reserve((size_t)doff[n] + 64));
     PG_HIP(c, c->d_hapx.reserve((size_t)doff[n] + 64));
     PG_HIP(c, c->d_hap_has_n.reserve(n));
     PG_HIP(c, c->d_hap_soff.reserve(n + 1));
@@ -281,9 +269,6 @@ int pg_haps_upload(pg_ctx* c, int n, const char* seq, const int64_t* off,
     PG_HIP(c, hipMemcpyAsync(c->d_hap_varlen.p, var_seq_len, n * 4, hipMemcpyHostToDevice, c->stream));
     const int cap = (int)c->table.size() - 1;
     const int grid = std::min(n, 65536);
-    hipLaunchKernelGGL(pg::k_pack_haps, dim3(grid), dim3(256), 0, c->stream, c->d_hap_raw.p, c->d_hap_soff.p,
-                       c->d_hap_doff.p, c->d_hap.p, c->d_run.p, n, pad, cap);
-    PG_HIP(c, hipGetLastError());
     hipLaunchKernelGGL(pg::k_pack_hapx, dim3(grid), dim3(256), 0, c->stream, c->d_hap_raw.p, c->d_hap_soff.p,
                        c->d_hap_doff.p, c->d_hapx.p, c->d_hap_has_n.p, n, pad, cap);
     PG_HIP(c, hipGetLastError());
@@ -452,10 +437,8 @@ int pg_pairs_upload(pg_ctx* c, int64_t np, const int32_t* hap_idx, const int32_t
     if (c->n_vote_haps > 0) {
         PG_HIP(c, c->d_vh_list.reserve(vh_list.size()));
         PG_HIP(c, c->d_vh_ptr.reserve(vh_ptr.size()));
-        PG_HIP(c, c->d_vh_pairs.reserve(vh_pairs.size()));
         PG_HIP(c, hipMemcpyAsync(c->d_vh_list.p, vh_list.data(), vh_list.size() * 4, hipMemcpyHostToDevice, c->stream));
         PG_HIP(c, hipMemcpyAsync(c->d_vh_ptr.p, vh_ptr.data(), vh_ptr.size() * 8, hipMemcpyHostToDevice, c->stream));
-        PG_HIP(c, hipMemcpyAsync(c->d_vh_pairs.p, vh_pairs.data(), vh_pairs.size() * 4, hipMemcpyHostToDevice, c->stream));
         PG_HIP(c, c->d_vh_recs.reserve(vh_recs.size()));
         PG_HIP(c, hipMemcpyAsync(c->d_vh_recs.p, vh_recs.data(), vh_recs.size() * sizeof(pg::VoteRec), hipMemcpyHostToDevice, c->stream));
     }
@@ -502,23 +485,13 @@ int pg_align_launch(pg_ctx* c) {
     PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_ANCHOR + 1], c->stream));
     c->ev_valid[PG_K_ANCHOR] = true;
 
-    pg::AlignArgs A;
-    A.hap = c->d_hap.p; A.run = c->d_run.p; A.hap_doff = c->d_hap_doff.p; A.hap_len = c->d_hap_len.p;
-    A.hap_start = c->d_hap_start.p; A.hap_varlen = c->d_hap_varlen.p;
-    A.rseq = c->d_rseq.p; A.rqual = c->d_rqual.p; A.roff = c->d_roff.p;
-    A.read_pos = c->d_read_pos.p; A.read_mapq = c->d_read_mapq.p;
-    A.pair_hap = c->d_pair_hap.p; A.pair_read = c->d_pair_read.p;
-    A.order = c->have_order ? c->d_order.p : nullptr;
-    A.waves = c->d_waves.p; A.anchor_in = c->d_anchor_in.p; A.tab4 = c->d_tab4.p;
-    A.exp_score = c->d_exp_score.p; A.exp_mapq = c->d_exp_mapq.p;
-    A.score = c->d_score.p; A.anchor = c->d_anchor.p; A.like = c->d_like.p;
-    A.n_waves = c->n_waves; A.ge4 = 4 * c->gapextend; A.np4 = 4 * c->nucprior;
     pg::Align2Args B;
     B.hapx = c->d_hapx.p; B.hap_xoff = c->d_hap_doff.p; B.hap_len = c->d_hap_len.p;
     B.hap_start = c->d_hap_start.p; B.hap_varlen = c->d_hap_varlen.p; B.hap_has_n = c->d_hap_has_n.p;
     B.readx = c->d_readx.p; B.read_xoff = c->d_read_xoff.p;
     B.read_pos = c->d_read_pos.p; B.read_mapq = c->d_read_mapq.p;
-    B.pair_hap = c->d_pair_hap.p; B.pair_read = c->d_pair_read.p; B.order = A.order;
+    B.pair_hap = c->d_pair_hap.p; B.pair_read = c->d_pair_read.p;
+    B.order = c->have_order ? c->d_order.p : nullptr;
     B.waves = c->d_waves.p; B.anchor_in = c->d_anchor_in.p; B.tab = c->d_tab1.p;
     B.exp_score = c->d_exp_score.p; B.exp_mapq = c->d_exp_mapq.p;
     B.score = c->d_score.p; B.anchor = c->d_anchor.p; B.like = c->d_like.p;
@@ -527,9 +500,7 @@ int pg_align_launch(pg_ctx* c) {
     if (c->lds_pad > 0)
         PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_align2), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_pad));
     PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_ALIGN], c->stream));
-    if (c->align_kernel == 1)
-        hipLaunchKernelGGL(pg::k_align, dim3((c->n_waves + 3) / 4), dim3(256), 0, c->stream, A);
-    else {
+    {
         PG_HIP(c, hipMemsetAsync(c->d_n_list.p, 0, 256, c->stream));
         hipLaunchKernelGGL(pg::k_align2, dim3((c->n_waves + 3) / 4), dim3(256), c->lds_pad, c->stream, B);
         PG_HIP(c, hipGetLastError());
