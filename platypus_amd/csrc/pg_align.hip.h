@@ -441,11 +441,13 @@ __global__ __launch_bounds__(256) void k_pack_hapx(const uint8_t* __restrict__ s
 }
 
 // readx[xoff[r] + j] = (char << 8) | quality for j < len, kPadElem up to xoff[r+1].
+// *bad_quality is set if any quality byte has its top bit set.
 __global__ __launch_bounds__(256) void k_pack_readx(const uint8_t* __restrict__ seq,
                                                     const uint8_t* __restrict__ qual,
                                                     const int64_t* __restrict__ roff,
                                                     const int64_t* __restrict__ xoff,
-                                                    uint16_t* __restrict__ dst, int n_reads)
+                                                    uint16_t* __restrict__ dst, int n_reads,
+                                                    int32_t* __restrict__ bad_quality)
 {
     const int wave = (int)((blockIdx.x * 256u + threadIdx.x) >> 6), lane = threadIdx.x & 63;
     const int n_waves = (int)(gridDim.x * 4u);
@@ -454,8 +456,14 @@ __global__ __launch_bounds__(256) void k_pack_readx(const uint8_t* __restrict__ 
         const int len = (int)(roff[r + 1] - s0);
         const int64_t d0 = xoff[r];
         const int tot = (int)(xoff[r + 1] - d0);
-        for (int j = lane; j < tot; j += 64)
-            dst[d0 + j] = j < len ? (uint16_t)(((uint32_t)seq[s0 + j] << 8) | qual[s0 + j]) : (uint16_t)kPadElem;
+        uint32_t seen = 0;
+        for (int j = lane; j < tot; j += 64) {
+            const uint32_t q = j < len ? qual[s0 + j] : 0u;
+            seen |= q;
+            dst[d0 + j] = j < len ? (uint16_t)(((uint32_t)seq[s0 + j] << 8) | q) : (uint16_t)kPadElem;
+        }
+        // qualities above 127 are outside the domain (the reference reads them as signed char)
+        if (seen & 0x80u) atomicOr(bad_quality, 1);
     }
 }
 

@@ -74,7 +74,7 @@ struct pg_ctx {
     DevBuf<uint16_t> d_readx;
     DevBuf<int64_t> d_roff, d_read_xoff, d_read2off;
     DevBuf<uint32_t> d_read2;           // 2-bit packed bases
-    DevBuf<int32_t> d_read_pos, d_read_mapq;
+    DevBuf<int32_t> d_read_pos, d_read_mapq, d_flag;
 
     // pairs
     int64_t n_pairs = 0;
@@ -195,7 +195,7 @@ int pg_ctx_destroy(pg_ctx* c) {
     c->d_hap_soff.release(); c->d_hap_doff.release();
     c->d_hap_len.release(); c->d_hap_start.release(); c->d_hap_varlen.release();
     c->d_rseq.release(); c->d_rqual.release(); c->d_roff.release();
-    c->d_read_pos.release(); c->d_read_mapq.release();
+    c->d_read_pos.release(); c->d_read_mapq.release(); c->d_flag.release();
     c->d_pair_hap.release(); c->d_pair_read.release(); c->d_order.release();
     c->d_vh_list.release(); c->d_anchor_in.release(); c->d_vh_ptr.release();
     c->d_n_list.release(); c->d_vh_recs.release(); c->d_waves.release(); c->d_score.release(); c->d_anchor.release(); c->d_like.release();
@@ -308,12 +308,8 @@ int pg_reads_upload(pg_ctx* c, int n, const char* seq, const char* qual, const i
         minl = std::min(minl, (int)l);
     }
     const int64_t total = off[n] - off[0];
-    {   // qualities are raw phred bytes; the reference reads them as signed char
-        const unsigned char* q = reinterpret_cast<const unsigned char*>(qual) + off[0];
-        unsigned char acc = 0;
-        for (int64_t i = 0; i < total; ++i) acc |= q[i];
-        if (acc & 0x80) return fail(c, PG_ERR_UNSUPPORTED, "a base quality above 127 was found");
-    }
+    PG_HIP(c, c->d_flag.reserve(64));
+    PG_HIP(c, hipMemsetAsync(c->d_flag.p, 0, 64 * sizeof(int32_t), c->stream));
     PG_HIP(c, c->d_rseq.reserve((size_t)total + 64));
     PG_HIP(c, c->d_rqual.reserve((size_t)total + 64));
     PG_HIP(c, c->d_roff.reserve(n + 1));
@@ -332,7 +328,7 @@ int pg_reads_upload(pg_ctx* c, int n, const char* seq, const char* qual, const i
     PG_HIP(c, hipMemcpyAsync(c->d_read_pos.p, pos, n * 4, hipMemcpyHostToDevice, c->stream));
     PG_HIP(c, hipMemcpyAsync(c->d_read_mapq.p, mapq, n * 4, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(pg::k_pack_readx, dim3(std::min((n + 3) / 4, 65536)), dim3(256), 0, c->stream, c->d_rseq.p,
-                       c->d_rqual.p, c->d_roff.p, c->d_read_xoff.p, c->d_readx.p, n);
+                       c->d_rqual.p, c->d_roff.p, c->d_read_xoff.p, c->d_readx.p, n, c->d_flag.p);
     PG_HIP(c, hipGetLastError());
     std::vector<int64_t> off2(n + 1);
     off2[0] = 0;
@@ -343,7 +339,10 @@ int pg_reads_upload(pg_ctx* c, int n, const char* seq, const char* qual, const i
     hipLaunchKernelGGL(pg::k_pack_codes, dim3(std::min((n + 3) / 4, 65536)), dim3(256), 0, c->stream, c->d_rseq.p,
                        c->d_roff.p, c->d_read2off.p, c->d_read2.p, n);
     PG_HIP(c, hipGetLastError());
+    int32_t bad = 0;
+    PG_HIP(c, hipMemcpyAsync(&bad, c->d_flag.p, sizeof bad, hipMemcpyDeviceToHost, c->stream));
     PG_HIP(c, hipStreamSynchronize(c->stream));
+    if (bad) return fail(c, PG_ERR_UNSUPPORTED, "a base quality above 127 was found");
     c->h_read_off.swap(roff);
     c->h_read2off.swap(off2);
     c->max_rlen = maxl;
