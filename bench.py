@@ -30,6 +30,21 @@ OPS_PER_CELL = 14          # int16 ALU operations per DP cell of the reference r
 NOMINAL_PEAK = 256 * 4 * 16 * 2 * 2.4e9   # CUs x SIMDs x lanes/clk x 2 packed x 2.4 GHz
 
 
+# Pair streams of the benchmark configurations: (haplotypes/window, reads/window, extra synth arguments, text).
+# --windows counts windows of the wgs shape; the other shapes are scaled to the same number of pairs.
+WORKLOADS = {
+    "wgs": (4, 32, dict(indel_hap_frac=0.25),
+            "wgs30x-like windows: %d windows x 4 haplotypes (~750 bp, 25%% of the variant haplotypes carry an "
+            "indel) x 32 reads of %d bp = %d pairs per GPU"),
+    "panel": (6, 128, dict(indel_hap_frac=1.0, homopolymers=True, n_frac=0.005),
+              "100x amplicon-panel-like windows: %d windows x 6 haplotypes (~750 bp with homopolymer runs of 5-40 "
+              "and 0.5%% N, every variant haplotype carries an indel) x 128 reads of %d bp = %d pairs per GPU"),
+    "joint": (257, 550, dict(indel_hap_frac=0.25),
+              "50-sample joint-calling-like windows: %d windows x 257 haplotypes (~750 bp) x 550 reads of %d bp "
+              "= %d pairs per GPU"),
+}
+
+
 def pmc_traffic(n_pairs, read_len):
     """HBM bytes per k_align2 launch from the committed counter passes (separate rocprofv3 --pmc runs of
     this same command; counters cannot be read from inside the process).  FETCH_SIZE and WRITE_SIZE are
@@ -61,6 +76,8 @@ def main():
     ap.add_argument("--windows", type=int, default=32768, help="windows per GPU (128 pairs each)")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="wgs",
+                    help="pair stream to synthesise; wgs is the configuration the metric is quoted on")
     args = ap.parse_args()
 
     from platypus_amd import shard
@@ -93,9 +110,10 @@ def main():
 
     from platypus_amd import native, synth
     L = args.read_len
-    batch = synth.make_batch(n_windows=args.windows, haps_per_window=4, reads_per_window=32,
-                             read_len=L, hap_len=750, indel_hap_frac=0.25,
-                             seed=synth.SEED + rank)
+    H, R, extra, text = WORKLOADS[args.workload]
+    n_windows = max(1, args.windows * 128 // (H * R))
+    batch = synth.make_batch(n_windows=n_windows, haps_per_window=H, reads_per_window=R,
+                             read_len=L, hap_len=750, seed=synth.SEED + rank, **extra)
     n_pairs = len(batch["pair_hap"])
     ctx = native.AlignContext(device)
     ctx.upload_batch(batch)                                    # inputs resident in HBM from here on
@@ -138,7 +156,7 @@ def main():
     score, anchor, like = ctx.fetch()
     peak = ctx.valu_int16_peak()
     achieved = algo_ops / k_avg
-    traffic, traffic_src = pmc_traffic(n_pairs, L)
+    traffic, traffic_src = pmc_traffic(n_pairs, L) if args.workload == "wgs" else (None, None)
     roofline = {
         "bound": "valu_int16",
         "kernel": "k_align2",
@@ -185,10 +203,9 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "int16", "data": "synthetic",
-        "config": {"workload": "wgs30x-like windows: %d windows x 4 haplotypes (~750 bp, 25%% of the "
-                               "variant haplotypes carry an indel) x 32 reads of %d bp = %d pairs per GPU; "
-                               "whole hot path (anchoring + banded DP + likelihood)" %
-                               (args.windows, L, n_pairs),
+        "config": {"workload": (text % (n_windows, L, n_pairs)) +
+                               "; whole hot path (anchoring + banded DP + likelihood)",
+                   "workload_name": args.workload,
                    "pairs_per_gpu": n_pairs, "read_len": L, "cells_per_pair": cells_per_pair,
                    "parallelism": "region shards, %d process(es), no collective" % world},
         "pairs_per_s": float(n_pairs) * world * args.steps / dt,

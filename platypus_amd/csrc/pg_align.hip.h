@@ -81,8 +81,7 @@ struct Align2Args {
     int32_t* score;
     int32_t* anchor;
     double* like;
-    int32_t* n_list;           // wavefronts left to the 'N'-aware kernel
-    int32_t* n_count;
+    uint8_t* n_flag;           // per wavefront: 1 = left to the 'N'-aware kernel
     int n_waves;
     int ge, np;
 };
@@ -124,6 +123,7 @@ struct Consts2 {
     u16 mge;      // -ge (mod 2^16)
     u16 inf;      // pos_inf
     u16 inf15;    // pos_inf + 15 P
+    u16 nadd;     // 1 - ('N' << 8)  (mod 2^16)
     uint32_t Ps;  // P again, as a scalar
 };
 
@@ -196,7 +196,10 @@ __device__ __forceinline__ void dp_iter(Lane2& L, int t, int len2, int e, uint32
 
     // ---- align.c:180-187: haplotype window, N limits and gap-open vector take position t+8 ----
     L.s1[J] = opaque((u16)(he & 0xff00u));
-    if (HASN) L.nq[J] = ((he & 0xff00u) == ((uint32_t)'N' << 8)) ? (u16)1 : C.inf;
+    // 'N' limit of the new column: 1 for an 'N', anything above the largest quality otherwise.
+    // (char << 8) + nadd wraps to exactly 1 for 'N' and to at least 0x101 for every other byte;
+    // a compare + select would bring 4-cycle instruction forms into the loop.
+    if (HASN) L.nq[J] = add16(L.s1[J], C.nadd);
     L.gP[J] = add16(gnew, C.P);
     L.gM[J] = add16(gnew, C.mge);
 
@@ -282,6 +285,7 @@ __device__ __forceinline__ u16 align_pair(const uint16_t* hx, const uint16_t* rx
     Consts2 C;
     C.geP = in_vgpr(ge_ + P); C.P = in_vgpr(P); C.mge = in_vgpr(0u - ge_);
     C.inf = in_vgpr(kInf); C.inf15 = in_vgpr(kInf + 15 * P); C.Ps = P;
+    C.nadd = in_vgpr(0x10001u - ((uint32_t)'N' << 8));
     Lane2 L;
     const uint2 h0 = load8_unaligned(hx), h1 = load8_unaligned(hx + 4);
 #pragma unroll
@@ -322,8 +326,8 @@ __device__ __forceinline__ u16 align_pair(const uint16_t* hx, const uint16_t* rx
 
 // The fast kernel (no 'N' handling, 128 VGPRs, 4 wavefronts per SIMD) takes every
 // wavefront; one whose pairs may meet an 'N' (the haplotype has one, or the
-// slice reaches the 'N' padding) only appends itself to `n_list` and leaves.
-// The second kernel walks that list with the full recurrence.
+// slice reaches the 'N' padding) only raises its flag and leaves.
+// The second kernel takes the flagged ones with the full recurrence.
 template <bool HASN>
 __device__ __forceinline__ void align_wave(const Align2Args& A, int wave, const uint8_t* s_tab)
 {
@@ -352,10 +356,9 @@ __device__ __forceinline__ void align_wave(const Align2Args& A, int wave, const 
     if (!HASN) {
         // an 'N' can only be met if the haplotype has one or the slice reaches the 'N' padding
         const bool need_n = A.hap_has_n[h] != 0 || a + len1 + 1 > hl;
-        if (__any(need_n)) {
-            if (lane == 0) A.n_list[atomicAdd(A.n_count, 1)] = wave;
-            return;
-        }
+        const bool handed_over = __any(need_n);
+        if (lane == 0) A.n_flag[wave] = handed_over ? 1 : 0;
+        if (handed_over) return;
     }
     const uint16_t* hx = A.hapx + A.hap_xoff[h] + a;
     const uint16_t* rx = A.readx + A.read_xoff[r];
@@ -378,7 +381,8 @@ __device__ __forceinline__ void align_wave(const Align2Args& A, int wave, const 
     }
 }
 
-__global__ __launch_bounds__(256) void k_align2(const Align2Args A)
+// 128 registers: four wavefronts per SIMD
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_align2(const Align2Args A)
 {
     __shared__ uint8_t s_tab[256];
     s_tab[threadIdx.x] = A.tab[threadIdx.x];
@@ -393,10 +397,14 @@ __global__ __launch_bounds__(256) void k_align2n(const Align2Args A)
     __shared__ uint8_t s_tab[256];
     s_tab[threadIdx.x] = A.tab[threadIdx.x];
     __syncthreads();
-    const int n = *A.n_count;         // written by the previous kernel on this stream
-    const int w0 = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256u + threadIdx.x) >> 6));
-    for (int i = w0; i < n; i += (int)gridDim.x * 4)
-        align_wave<true>(A, A.n_list[i], s_tab);
+    // Same grid as k_align2; a wavefront runs if the previous kernel on this stream
+    // raised its flag.  (A compacted work list costs one atomic per entry on a single
+    // address, which serialises for longer than the listed work takes when most
+    // wavefronts are listed; a persistent grid walking the flags ran 20 % slower
+    // than letting the dispatcher place one short-lived wavefront per entry.)
+    const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256u + threadIdx.x) >> 6));
+    if (wave >= A.n_waves || !A.n_flag[wave]) return;
+    align_wave<true>(A, wave, s_tab);
 }
 
 // ---------------------------------------------------------------------------

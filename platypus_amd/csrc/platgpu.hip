@@ -81,7 +81,8 @@ struct pg_ctx {
     int n_waves = 0;
     int n_vote_haps = 0;
     bool have_order = false;
-    DevBuf<int32_t> d_pair_hap, d_pair_read, d_order, d_vh_list, d_anchor_in, d_n_list;
+    DevBuf<int32_t> d_pair_hap, d_pair_read, d_order, d_vh_list, d_anchor_in;
+    DevBuf<uint8_t> d_n_flag;
     DevBuf<int64_t> d_vh_ptr;
     DevBuf<pg::WaveDesc> d_waves;
     DevBuf<pg::VoteRec> d_vh_recs;
@@ -198,7 +199,7 @@ int pg_ctx_destroy(pg_ctx* c) {
     c->d_read_pos.release(); c->d_read_mapq.release(); c->d_flag.release();
     c->d_pair_hap.release(); c->d_pair_read.release(); c->d_order.release();
     c->d_vh_list.release(); c->d_anchor_in.release(); c->d_vh_ptr.release();
-    c->d_n_list.release(); c->d_vh_recs.release(); c->d_waves.release(); c->d_score.release(); c->d_anchor.release(); c->d_like.release();
+    c->d_n_flag.release(); c->d_vh_recs.release(); c->d_waves.release(); c->d_score.release(); c->d_anchor.release(); c->d_like.release();
     c->d_g1.release(); c->d_g2.release(); c->d_gn.release(); c->d_gout.release();
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -425,7 +426,7 @@ int pg_pairs_upload(pg_ctx* c, int64_t np, const int32_t* hap_idx, const int32_t
     PG_HIP(c, c->d_anchor.reserve(np));
     PG_HIP(c, c->d_anchor_in.reserve(np));
     PG_HIP(c, c->d_like.reserve(np));
-    PG_HIP(c, c->d_n_list.reserve(waves.size() + 1));   // [0] = count, [1..] = wavefront ids
+    PG_HIP(c, c->d_n_flag.reserve(waves.size() + 64));
     PG_HIP(c, hipMemcpyAsync(c->d_pair_hap.p, hap_idx, np * 4, hipMemcpyHostToDevice, c->stream));
     PG_HIP(c, hipMemcpyAsync(c->d_pair_read.p, read_idx, np * 4, hipMemcpyHostToDevice, c->stream));
     PG_HIP(c, hipMemcpyAsync(c->d_waves.p, waves.data(), waves.size() * sizeof(pg::WaveDesc), hipMemcpyHostToDevice, c->stream));
@@ -494,16 +495,15 @@ int pg_align_launch(pg_ctx* c) {
     B.waves = c->d_waves.p; B.anchor_in = c->d_anchor_in.p; B.tab = c->d_tab1.p;
     B.exp_score = c->d_exp_score.p; B.exp_mapq = c->d_exp_mapq.p;
     B.score = c->d_score.p; B.anchor = c->d_anchor.p; B.like = c->d_like.p;
-    B.n_count = c->d_n_list.p; B.n_list = c->d_n_list.p + 1;
+    B.n_flag = c->d_n_flag.p;
     B.n_waves = c->n_waves; B.ge = c->gapextend; B.np = c->nucprior;
     if (c->lds_pad > 0)
         PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_align2), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_pad));
     PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_ALIGN], c->stream));
     {
-        PG_HIP(c, hipMemsetAsync(c->d_n_list.p, 0, 256, c->stream));
         hipLaunchKernelGGL(pg::k_align2, dim3((c->n_waves + 3) / 4), dim3(256), c->lds_pad, c->stream, B);
         PG_HIP(c, hipGetLastError());
-        hipLaunchKernelGGL(pg::k_align2n, dim3(std::min((c->n_waves + 3) / 4, 2048)), dim3(256), 0, c->stream, B);
+        hipLaunchKernelGGL(pg::k_align2n, dim3((c->n_waves + 3) / 4), dim3(256), 0, c->stream, B);
     }
     PG_HIP(c, hipGetLastError());
     PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_ALIGN + 1], c->stream));
