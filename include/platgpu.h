@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 1
+#define PG_ABI_VERSION 2
 
 enum {
     PG_OK = 0,
@@ -41,7 +41,7 @@ enum {
 #define PG_MAX_HASHED_HAP_LEN 16383
 
 /* kernel ids for pg_kernel_time_ms */
-enum { PG_K_ANCHOR = 0, PG_K_ALIGN = 1, PG_K_GENOTYPE = 2, PG_K_COUNT = 3 };
+enum { PG_K_ANCHOR = 0, PG_K_ALIGN = 1, PG_K_GENOTYPE = 2, PG_K_CALLER_SETUP = 3, PG_K_CALLER_EM = 4, PG_K_COUNT = 5 };
 
 typedef struct pg_ctx pg_ctx;
 
@@ -134,7 +134,7 @@ int pg_align_pairs(pg_ctx *ctx, int64_t n_pairs, const int32_t *hap_idx, const i
 
 /*
  * Device time in milliseconds of kernel group `which` in the last
- * pg_align_launch / pg_genotype_loglik, measured with HIP events on the
+ * pg_align_launch / pg_genotype_loglik / pg_caller_launch, measured with HIP events on the
  * context's stream.  Synchronises.
  */
 int pg_kernel_time_ms(pg_ctx *ctx, int which, float *ms);
@@ -150,6 +150,66 @@ int pg_kernel_time_ms(pg_ctx *ctx, int which, float *ms);
  */
 int pg_genotype_loglik(pg_ctx *ctx, int64_t n_gen, const int64_t *pair_base1,
                        const int64_t *pair_base2, const int32_t *n_reads, double *out);
+
+/*
+ * ---- The stage that consumes the likelihood matrix: Caller.setup / Caller.call /
+ * ---- Population.calculatePosterior of platypus/cpopulation.pyx, batched over windows.
+ *
+ * pg_windows_upload describes the windows of the uploaded pair list.  Window w
+ * has n_haps[w] haplotypes (1..1000, platypus/cpopulation.pyx:546) and
+ * n_inds[w] individuals (the `haplotypes` and `readBuffers` arguments of
+ * Caller.setup, platypus/cpopulation.pyx:658); its pairs must form one dense,
+ * haplotype-major block of the pair list starting at pair like_base[w]:
+ * pair(h, r) = like_base[w] + h * n_reads + r.  ind_read_off holds, window after
+ * window, n_inds[w] + 1 ascending read offsets inside that block (first 0, last
+ * n_reads): individual i owns reads [off[i], off[i+1]) -- the
+ * [windowStart, windowEnd) range of its bamReadBuffer (platypus/cpopulation.pyx:702-704).
+ * Genotypes are implied: all pairs (a <= b) of the window's haplotypes in the
+ * order of generateAllGenotypesFromHaplotypeList (platypus/cgenotype.pyx:90-96),
+ * the only generator the reference uses (platypus/variantcaller.pyx:153,178).
+ * A window in which no individual has a read is refused (the reference divides
+ * by zero there, platypus/cpopulation.pyx:883).
+ */
+int pg_windows_upload(pg_ctx *ctx, int n_windows, const int32_t *n_haps, const int32_t *n_inds,
+                      const int64_t *like_base, const int32_t *ind_read_off);
+
+/*
+ * Enqueue, after pg_align_launch on the same stream, for every window:
+ * Caller.setup (platypus/cpopulation.pyx:696-734: genotype log-likelihoods with
+ * DiploidGenotype.calculateDataLikelihood, platypus/cgenotype.pyx:48-63, one
+ * maximum per window, exp(ll - max)) and Caller.call (platypus/cpopulation.pyx:741-805:
+ * EM iterations, platypus/cpopulation.pyx:807-890, until the largest frequency
+ * change is <= eps or max_iters is reached -- the reference uses 100 -- then the
+ * genotype with the largest csr value per individual).  Likelihoods never leave
+ * the device.  Sums over genotypes are regrouped, so results agree with the
+ * reference's doubles to rounding (tests: 1e-9 relative), not bit for bit.
+ */
+int pg_caller_launch(pg_ctx *ctx, int max_iters);
+
+/*
+ * Results of the last pg_caller_launch (synchronises); any output may be NULL.
+ *   freq            concatenated over windows, n_haps[w] each: Population.frequencies
+ *   iters           per window: EM iterations run
+ *   max_change      per window: last maximum frequency change
+ *   best_genotype   concatenated, n_inds[w] each: index of the called genotype in
+ *                   the implied order, -1 for an individual without reads
+ *                   (genotypeCalls None, platypus/cpopulation.pyx:777-780)
+ *   best_value      its csr value (genotypeLikelihoods, platypus/cpopulation.pyx:797)
+ *   genotype_post   concatenated, n_inds[w] x n_gen[w] each: the normalised
+ *                   genotype likelihoods (genotypePosteriors, platypus/cpopulation.pyx:734)
+ */
+int pg_caller_fetch(pg_ctx *ctx, double *freq, int32_t *iters, double *max_change,
+                    int32_t *best_genotype, double *best_value, double *genotype_post);
+
+/*
+ * Population.calculatePosterior (platypus/cpopulation.pyx:515-632) for n_vars
+ * variants against the results of the last pg_caller_launch.  var_window[v] is
+ * the variant's window; hap_has_var holds, variant after variant, one byte per
+ * haplotype of that window (non-zero: the variant is among the haplotype's
+ * variants, platypus/cpopulation.pyx:562); prior[v] is var.calculatePrior().
+ */
+int pg_variant_posteriors(pg_ctx *ctx, int n_vars, const int32_t *var_window,
+                          const uint8_t *hap_has_var, const double *prior, double *out);
 
 /*
  * Measured issue rate of the packed 16-bit integer VALU instructions the

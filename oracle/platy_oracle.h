@@ -47,6 +47,19 @@ typedef struct {
 void po_run_pairs(const po_batch *b, long lo, long hi, po_align_fn ext_align,
                   int *out_score, int *out_anchor);
 
+/* ---- genotype likelihood / EM / variant posterior stage (platy_caller_oracle.c) ----
+ * window matrix like[h * n_reads + r]; individual i owns reads [ind_read_off[i], ind_read_off[i+1]);
+ * genotypes in the order of platypus/cgenotype.pyx:90-96 */
+int po_n_genotypes(int n_hap);
+void po_genotype_indexes(int n_hap, int32_t *h1, int32_t *h2);
+void po_caller_setup(int n_hap, int n_ind, int n_reads, const int32_t *ind_read_off,
+                     const double *like, double *post);
+int po_caller_call(int n_hap, int n_ind, const int32_t *ind_read_off, const double *post,
+                   int max_iters, int literal, double *freq, double *cisr_out,
+                   double *max_change_out, int32_t *best_gen, double *best_val);
+double po_variant_posterior(int n_hap, int n_ind, const int32_t *ind_read_off, const double *post,
+                            const double *freq, const uint8_t *hap_has_var, double prior);
+
 #ifdef __cplusplus
 }
 #endif

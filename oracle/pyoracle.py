@@ -68,6 +68,16 @@ def lib():
         L.po_run_pairs.restype = None
         L.po_run_pairs.argtypes = [C.POINTER(_Batch), C.c_long, C.c_long, C.c_void_p,
                                    C.c_void_p, C.c_void_p]
+        L.po_n_genotypes.restype = C.c_int
+        L.po_n_genotypes.argtypes = [C.c_int]
+        L.po_caller_setup.restype = None
+        L.po_caller_setup.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.po_caller_call.restype = C.c_int
+        L.po_caller_call.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                     C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_void_p, C.c_void_p]
+        L.po_variant_posterior.restype = C.c_double
+        L.po_variant_posterior.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_double]
         _lib = L
     return _lib
 
@@ -182,3 +192,46 @@ def run_pairs(batch, use_ref=False, threads=1, reuse_hash=False, lo=0, hi=None,
         for t in ts:
             t.join()
     return score[lo:hi], anchor[lo:hi]
+
+
+# ---- genotype likelihood / EM / variant posterior stage (platypus/cpopulation.pyx) ----
+
+def caller_setup(like, ind_read_off):
+    """Caller.setup (cpopulation.pyx:658-739): like is the window's [n_hap, n_reads] likelihood matrix;
+    returns the normalised genotype likelihoods [n_ind, n_gen]."""
+    like = np.ascontiguousarray(like, dtype=np.float64)
+    off = np.ascontiguousarray(ind_read_off, dtype=np.int32)
+    n_hap, n_reads = like.shape
+    n_ind = len(off) - 1
+    post = np.zeros((n_ind, lib().po_n_genotypes(n_hap)), dtype=np.float64)
+    lib().po_caller_setup(n_hap, n_ind, n_reads, off.ctypes.data, like.ctypes.data, post.ctypes.data)
+    return post
+
+
+def caller_call(post, ind_read_off, n_hap, max_iters=100, literal=False, want_cisr=False):
+    """Caller.call (cpopulation.pyx:741-805): returns dict(freq, iters, max_change, best_gen, best_val[, cisr])."""
+    post = np.ascontiguousarray(post, dtype=np.float64)
+    off = np.ascontiguousarray(ind_read_off, dtype=np.int32)
+    n_ind = len(off) - 1
+    freq = np.zeros(n_hap, dtype=np.float64)
+    cisr = np.zeros_like(post) if want_cisr else None
+    mc = C.c_double(0.0)
+    best = np.zeros(n_ind, dtype=np.int32)
+    val = np.zeros(n_ind, dtype=np.float64)
+    iters = lib().po_caller_call(n_hap, n_ind, off.ctypes.data, post.ctypes.data, max_iters, int(literal),
+                                 freq.ctypes.data, cisr.ctypes.data if want_cisr else None, C.byref(mc),
+                                 best.ctypes.data, val.ctypes.data)
+    out = dict(freq=freq, iters=iters, max_change=mc.value, best_gen=best, best_val=val)
+    if want_cisr:
+        out["cisr"] = cisr
+    return out
+
+
+def variant_posterior(post, ind_read_off, freq, hap_has_var, prior):
+    """Population.calculatePosterior (cpopulation.pyx:515-632)."""
+    post = np.ascontiguousarray(post, dtype=np.float64)
+    off = np.ascontiguousarray(ind_read_off, dtype=np.int32)
+    freq = np.ascontiguousarray(freq, dtype=np.float64)
+    m = np.ascontiguousarray(hap_has_var, dtype=np.uint8)
+    return lib().po_variant_posterior(len(freq), len(off) - 1, off.ctypes.data, post.ctypes.data,
+                                      freq.ctypes.data, m.ctypes.data, float(prior))

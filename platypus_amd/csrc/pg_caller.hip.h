@@ -1,0 +1,321 @@
+// Device kernels of the stage that consumes the likelihood matrix: genotype
+// log-likelihoods, their normalisation, the EM for haplotype frequencies with
+// the per-individual genotype calls, and variant posteriors
+// (platypus/cpopulation.pyx:658-890 and :515-632).  All fp64.
+//
+// A window w has n_hap haplotypes, n_ind individuals and a dense likelihood
+// matrix like[like_base + h * n_reads + r]; individual i owns the reads
+// [ioff[i], ioff[i+1]).  Genotypes are the pairs (a <= b) in the order of
+// platypus/cgenotype.pyx:90-96; packed index of (a, b): a n - a (a - 1) / 2 + b - a.
+//
+//   k_gl          log-likelihood of every (individual, genotype)
+//   k_post_norm   one maximum per window, exp(ll - max); also written as full
+//                 symmetric n x n matrices, the layout the EM streams
+//   k_em          EM iterations and genotype calls, one workgroup per window
+//   k_var_post    posterior of a variant given the haplotypes that carry it
+//
+// Sums over reads run in read order like the reference's; sums over genotypes
+// are regrouped (see k_em), so results agree with the reference to rounding,
+// not bit for bit; every reduction has a fixed shape, so runs are reproducible.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pg {
+
+struct WinDesc {
+    int32_t n_hap, n_ind, n_reads, n_gen;
+    int64_t like_base;   // pair index of (haplotype 0, read 0)
+    int64_t ioff_base;   // into the concatenated per-individual read offsets (n_ind + 1 entries)
+    int64_t cell_base;   // into per-(individual, genotype) arrays: sum of n_ind * n_gen of the windows before
+    int64_t full_base;   // into the full matrices: sum of n_ind * n_hap^2 before
+    int64_t hap_base;    // into per-haplotype outputs
+    int64_t ind_base;    // into per-individual outputs
+};
+
+__device__ __forceinline__ int64_t tri_row_start(int a, int n) { return (int64_t)a * n - (int64_t)a * (a - 1) / 2; }
+
+// row a of packed index g: largest a with tri_row_start(a) <= g
+__device__ __forceinline__ int tri_row_of(int g, int n) {
+    const double t = 2.0 * n + 1.0;
+    int a = (int)((t - sqrt(t * t - 8.0 * (double)g)) * 0.5);
+    a = a < 0 ? 0 : (a > n - 1 ? n - 1 : a);
+    while (a > 0 && tri_row_start(a, n) > g) --a;
+    while (a + 1 < n && tri_row_start(a + 1, n) <= g) ++a;
+    return a;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {       // fixed butterfly: same result in every lane
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// k_gl: ll[cell] = sum over the individual's reads, in read order, of
+// log(0.5 (L[a][r] + L[b][r]))  (platypus/cgenotype.pyx:58-61).  One thread per
+// (window, individual, genotype) cell; an individual without reads keeps 0.0
+// (platypus/cpopulation.pyx:717-718).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gl(const WinDesc* __restrict__ wins, int n_win,
+                                            const int32_t* __restrict__ ioff,
+                                            const double* __restrict__ like,
+                                            double* __restrict__ ll, int64_t n_cells)
+{
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= n_cells) return;
+    int lo = 0, hi = n_win - 1;                      // last window with cell_base <= c
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (wins[mid].cell_base <= c) lo = mid; else hi = mid - 1;
+    }
+    const WinDesc W = wins[lo];
+    const int64_t rem = c - W.cell_base;
+    const int i = (int)(rem / W.n_gen), g = (int)(rem % W.n_gen);
+    const int a = tri_row_of(g, W.n_hap), b = a + (int)(g - tri_row_start(a, W.n_hap));
+    const int r0 = ioff[W.ioff_base + i], nr = ioff[W.ioff_base + i + 1] - r0;
+    const double* l1 = like + W.like_base + (int64_t)a * W.n_reads + r0;
+    const double* l2 = like + W.like_base + (int64_t)b * W.n_reads + r0;
+    double s = 0.0;
+    for (int r = 0; r < nr; ++r) s += log(0.5 * (l1[r] + l2[r]));
+    ll[c] = s;
+}
+
+// ---------------------------------------------------------------------------
+// k_post_norm: platypus/cpopulation.pyx:696,722-734.  One workgroup per window:
+// maximum log-likelihood over the cells of individuals with reads (start value
+// -1e7), then post = exp(ll - max) for every cell, in place, and mirrored into
+// the full matrices full[i][a][b] = full[i][b][a].
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_post_norm(const WinDesc* __restrict__ wins,
+                                                   const int32_t* __restrict__ ioff,
+                                                   double* __restrict__ cells, double* __restrict__ full)
+{
+    __shared__ double s_red[4];
+    const WinDesc W = wins[blockIdx.x];
+    const int tid = threadIdx.x, n = W.n_hap;
+    const int64_t total = (int64_t)W.n_ind * W.n_gen;
+    double mx = -1e7;
+    for (int64_t k = tid; k < total; k += 256) {
+        const int i = (int)(k / W.n_gen);
+        if (ioff[W.ioff_base + i + 1] != ioff[W.ioff_base + i]) mx = fmax(mx, cells[W.cell_base + k]);
+    }
+    mx = wave_max(mx);
+    if ((tid & 63) == 0) s_red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
+    for (int64_t k = tid; k < total; k += 256) {
+        const int i = (int)(k / W.n_gen), g = (int)(k % W.n_gen);
+        const double p = exp(cells[W.cell_base + k] - mx);
+        cells[W.cell_base + k] = p;
+        const int a = tri_row_of(g, n), b = a + (int)(g - tri_row_start(a, n));
+        double* F = full + W.full_base + (int64_t)i * n * n;
+        F[(int64_t)a * n + b] = p;
+        F[(int64_t)b * n + a] = p;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_em: Caller.call + EMiteration, platypus/cpopulation.pyx:741-890.
+//
+// With P the symmetric matrix of an individual's normalised genotype
+// likelihoods and f the frequencies, the reference's per-genotype terms
+//     csr(a,b) = P(a,b) f_a f_b (1 + (a != b)),  csrSum = sum csr     (:847-849)
+// and the per-haplotype totals of :869-880 regroup to a matrix-vector product:
+//     y = P f,   csrSum = f . y,   total_k = sum_i 2 f_k y_k / csrSum_i ,
+// O(n_hap^2) per individual and iteration instead of O(n_hap^3).  One
+// wavefront takes an individual at a time (lanes over k, a sequential loop over
+// the rows of the full matrix, which adjacent lanes read at adjacent addresses);
+// the wavefronts' partial totals are added in wavefront order.
+//
+// The genotype calls (:773-797) use the csr values of the LAST iteration, i.e.
+// the frequencies before its update; they are recomputed from those at the end.
+// LDS: f, f_prev, f_new [n_max] | per wavefront: y [n_max], acc [n_max].
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_em(const WinDesc* __restrict__ wins,
+                                             const int32_t* __restrict__ ioff,
+                                             const double* __restrict__ full,
+                                             int max_iters, int n_max,
+                                             double* __restrict__ freq_out, int32_t* __restrict__ iters_out,
+                                             double* __restrict__ change_out, int32_t* __restrict__ best_gen,
+                                             double* __restrict__ best_val)
+{
+    extern __shared__ double em_lds[];
+    __shared__ double s_red[16];
+    __shared__ int s_with_data;
+    const WinDesc W = wins[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_thr = blockDim.x, n_wav = n_thr >> 6;
+    const int n = W.n_hap;
+    double* f = em_lds;
+    double* f_prev = f + n_max;
+    double* f_new = f_prev + n_max;
+    double* yv = f_new + n_max + (size_t)wave * 2 * n_max;
+    double* acc = yv + n_max;
+    const int32_t* io = ioff + W.ioff_base;
+
+    if (tid == 0) {
+        int c = 0;
+        for (int i = 0; i < W.n_ind; ++i) c += io[i + 1] != io[i];
+        s_with_data = c;
+    }
+    for (int k = tid; k < n; k += n_thr) f[k] = 1.0 / n;                    // :753,763-764
+    __syncthreads();
+    const int n_with_data = s_with_data;
+    double eps = 1.0 / (W.n_ind * 2 * 2);                                    // :751
+    eps = eps < 1e-3 ? eps : 1e-3;
+    double max_change = eps + 1;
+    int iters = 0;
+
+    // y = P_i f_src and csrSum = f_src . y for individual i, by this wavefront
+    auto matvec = [&](int i, const double* f_src) -> double {
+        const double* P = full + W.full_base + (int64_t)i * n * n;
+        double part = 0.0;
+        for (int k0 = 0; k0 < n; k0 += 64) {
+            const int k = k0 + lane;
+            double y = 0.0;
+            if (k < n) {
+                for (int r = 0; r < n; ++r) y += P[(int64_t)r * n + k] * f_src[r];
+                yv[k] = y;
+                part += f_src[k] * y;
+            }
+        }
+        return wave_sum(part);
+    };
+
+    while (max_change > eps && iters < max_iters) {                          // :766-768
+        for (int k = lane; k < n; k += 64) acc[k] = 0.0;
+        for (int i = wave; i < W.n_ind; i += n_wav) {
+            if (io[i + 1] == io[i]) continue;                                // :834-835
+            const double s = matvec(i, f);
+            for (int k = lane; k < n; k += 64) {
+                const double t = 2.0 * f[k] * yv[k];
+                acc[k] += s > 0.0 ? t / s : t;                               // :852-854
+            }
+        }
+        __syncthreads();
+        double ch = 0.0;
+        for (int k = tid; k < n; k += n_thr) {
+            double t = 0.0;
+            for (int w = 0; w < n_wav; ++w) t += em_lds[(size_t)3 * n_max + (size_t)w * 2 * n_max + n_max + k];
+            const double nf = t / (2 * n_with_data);                         // :883
+            f_new[k] = nf;
+            ch = fmax(ch, fabs(f[k] - nf));                                  // :885-888
+        }
+        ch = wave_max(ch);
+        if (lane == 0) s_red[wave] = ch;
+        __syncthreads();
+        ch = 0.0;
+        for (int w = 0; w < n_wav; ++w) ch = fmax(ch, s_red[w]);
+        max_change = ch;
+        for (int k = tid; k < n; k += n_thr) { f_prev[k] = f[k]; f[k] = f_new[k]; }
+        ++iters;
+        __syncthreads();
+    }
+
+    for (int k = tid; k < n; k += n_thr) freq_out[W.hap_base + k] = f[k];
+    if (tid == 0) { iters_out[blockIdx.x] = iters; change_out[blockIdx.x] = max_change; }
+
+    // genotype calls from the last iteration's csr values: first maximum in genotype order
+    for (int i = wave; i < W.n_ind; i += n_wav) {
+        if (io[i + 1] == io[i]) {                                            // :777-780
+            if (lane == 0) { best_gen[W.ind_base + i] = -1; best_val[W.ind_base + i] = 0.0; }
+            continue;
+        }
+        if (iters == 0) {                                                    // csr still all zero (calloc, :701)
+            if (lane == 0) { best_gen[W.ind_base + i] = 0; best_val[W.ind_base + i] = 0.0; }
+            continue;
+        }
+        const double s = matvec(i, f_prev);
+        const double* P = full + W.full_base + (int64_t)i * n * n;
+        double bv = 0.0;
+        int bj = 0x7fffffff;
+        for (int a = 0; a < n; ++a) {
+            const int64_t row = tri_row_start(a, n);
+            for (int b = a + lane; b < n; b += 64) {
+                double v = P[(int64_t)a * n + b] * f_prev[a] * f_prev[b] * (1 + (a != b));   // :847
+                if (s > 0.0) v /= s;
+                const int j = (int)(row + b - a);
+                if (bj == 0x7fffffff || v > bv) { bv = v; bj = j; }          // :791 within the lane: j ascending
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ov = __shfl_xor(bv, off);
+            const int oj = __shfl_xor(bj, off);
+            if (oj != 0x7fffffff && (bj == 0x7fffffff || ov > bv || (ov == bv && oj < bj))) { bv = ov; bj = oj; }
+        }
+        if (lane == 0) { best_gen[W.ind_base + i] = bj; best_val[W.ind_base + i] = bv; }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_var_post: Population.calculatePosterior, platypus/cpopulation.pyx:515-632.
+// One wavefront per variant.  has_var marks the haplotypes that carry the
+// variant; f' = f restricted to the others and rescaled (:554-580).  Per
+// individual the two sums over genotypes (:597-614) are f.(P f) and f'.(P f').
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_var_post(const WinDesc* __restrict__ wins,
+                                                 const int32_t* __restrict__ ioff,
+                                                 const double* __restrict__ full,
+                                                 const double* __restrict__ freq,
+                                                 const int32_t* __restrict__ var_win,
+                                                 const int64_t* __restrict__ var_mask_off,
+                                                 const uint8_t* __restrict__ has_var,
+                                                 const double* __restrict__ prior,
+                                                 double* __restrict__ out, int n_max)
+{
+    extern __shared__ double vp_lds[];
+    double* f = vp_lds;
+    double* fp = f + n_max;
+    const int v = blockIdx.x, lane = threadIdx.x;
+    const WinDesc W = wins[var_win[v]];
+    const int n = W.n_hap;
+    const uint8_t* m = has_var + var_mask_off[v];
+    const int32_t* io = ioff + W.ioff_base;
+    double part = 0.0;
+    for (int k = lane; k < n; k += 64) {
+        const double fk = freq[W.hap_base + k];
+        f[k] = fk;
+        fp[k] = m[k] ? 0.0 : fk;
+        part += fp[k];
+    }
+    const double sum_freqs = wave_sum(part);
+    __builtin_amdgcn_wave_barrier();
+    if (sum_freqs > 0)
+        for (int k = lane; k < n; k += 64)
+            if (fp[k] != 0.0) fp[k] /= sum_freqs;
+    __builtin_amdgcn_wave_barrier();
+    double slp_var = 0.0, slp_novar = 0.0;
+    for (int i = 0; i < W.n_ind; ++i) {
+        if (io[i + 1] == io[i]) continue;                                    // :590-591
+        const double* P = full + W.full_base + (int64_t)i * n * n;
+        double pv = 0.0, pn = 0.0;
+        for (int k = lane; k < n; k += 64) {
+            double y = 0.0, yp = 0.0;
+            for (int r = 0; r < n; ++r) {
+                const double p = P[(int64_t)r * n + k];
+                y += p * f[r];
+                yp += p * fp[r];
+            }
+            pv += f[k] * y;
+            pn += fp[k] * yp;
+        }
+        pv = wave_sum(pv);
+        pn = wave_sum(pn);
+        slp_var += pv > 0 ? log(pv) : -708.0;                                // :616-624
+        slp_novar += pn > 0 ? log(pn) : -708.0;
+    }
+    if (lane == 0) {
+        const double ratio = exp(slp_novar - slp_var);                       // :626-627
+        const double pr = prior[v];
+        out[v] = pr / (pr + ratio * (1.0 - pr));
+    }
+}
+
+}  // namespace pg

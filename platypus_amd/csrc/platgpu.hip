@@ -15,6 +15,7 @@
 #include "../../include/platgpu.h"
 #include "pg_kernels.hip.h"
 #include "pg_align.hip.h"
+#include "pg_caller.hip.h"
 
 namespace {
 
@@ -91,6 +92,17 @@ struct pg_ctx {
     bool launched = false;
     DevBuf<int32_t> d_score, d_anchor;
     DevBuf<double> d_like;
+
+    // windows of the genotype / EM stage
+    int n_windows = 0, max_win_haps = 0, max_win_inds = 0;
+    int64_t win_cells = 0, win_full = 0, win_haps_total = 0, win_inds_total = 0;
+    bool caller_done = false;
+    std::vector<pg::WinDesc> h_wins;
+    DevBuf<pg::WinDesc> d_wins;
+    DevBuf<int32_t> d_ioff, d_em_iters, d_best_gen, d_var_win;
+    DevBuf<double> d_cells, d_full, d_freq, d_em_change, d_best_val, d_var_prior, d_var_out;
+    DevBuf<int64_t> d_var_moff;
+    DevBuf<uint8_t> d_var_mask;
 
     // genotype scratch
     DevBuf<int64_t> d_g1, d_g2;
@@ -199,7 +211,9 @@ int pg_ctx_destroy(pg_ctx* c) {
     c->d_read_pos.release(); c->d_read_mapq.release(); c->d_flag.release();
     c->d_pair_hap.release(); c->d_pair_read.release(); c->d_order.release();
     c->d_vh_list.release(); c->d_anchor_in.release(); c->d_vh_ptr.release();
-    c->d_n_flag.release(); c->d_vh_recs.release(); c->d_waves.release(); c->d_score.release(); c->d_anchor.release(); c->d_like.release();
+    c->d_n_flag.release(); c->d_wins.release(); c->d_ioff.release(); c->d_em_iters.release(); c->d_best_gen.release();
+    c->d_var_win.release(); c->d_cells.release(); c->d_full.release(); c->d_freq.release(); c->d_em_change.release();
+    c->d_best_val.release(); c->d_var_prior.release(); c->d_var_out.release(); c->d_var_moff.release(); c->d_var_mask.release(); c->d_vh_recs.release(); c->d_waves.release(); c->d_score.release(); c->d_anchor.release(); c->d_like.release();
     c->d_g1.release(); c->d_g2.release(); c->d_gn.release(); c->d_gout.release();
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -574,6 +588,133 @@ int pg_genotype_loglik(pg_ctx* c, int64_t ng, const int64_t* b1, const int64_t* 
     c->ev_valid[PG_K_GENOTYPE] = true;
     PG_HIP(c, hipMemcpyAsync(out, c->d_gout.p, ng * 8, hipMemcpyDeviceToHost, c->stream));
     PG_HIP(c, hipStreamSynchronize(c->stream));
+    return PG_OK;
+}
+
+int pg_windows_upload(pg_ctx* c, int nw, const int32_t* n_haps, const int32_t* n_inds,
+                      const int64_t* like_base, const int32_t* ind_read_off) {
+    if (!c) return PG_ERR_INVALID;
+    if (nw < 0 || (nw > 0 && (!n_haps || !n_inds || !like_base || !ind_read_off)))
+        return fail(c, PG_ERR_INVALID, "pg_windows_upload: bad arguments");
+    c->caller_done = false;
+    std::vector<pg::WinDesc> wins((size_t)nw);
+    int64_t ioff = 0, cells = 0, full = 0, haps = 0, inds = 0;
+    int max_h = 0, max_i = 0;
+    for (int w = 0; w < nw; ++w) {
+        const int nh = n_haps[w], ni = n_inds[w];
+        if (nh < 1 || nh > 1000)
+            return fail(c, PG_ERR_UNSUPPORTED, "window %d has %d haplotypes (1..1000, cpopulation.pyx:546)", w, nh);
+        if (ni < 1) return fail(c, PG_ERR_INVALID, "window %d has %d individuals", w, ni);
+        const int32_t* o = ind_read_off + ioff;
+        if (o[0] != 0) return fail(c, PG_ERR_INVALID, "window %d: read offsets must start at 0", w);
+        for (int i = 0; i < ni; ++i)
+            if (o[i + 1] < o[i]) return fail(c, PG_ERR_INVALID, "window %d: read offsets must ascend", w);
+        const int nr = o[ni];
+        if (nr == 0)
+            return fail(c, PG_ERR_UNSUPPORTED, "window %d has no reads (the reference divides by zero, cpopulation.pyx:883)", w);
+        if (like_base[w] < 0 || like_base[w] + (int64_t)nh * nr > c->n_pairs)
+            return fail(c, PG_ERR_INVALID, "window %d reaches outside the pair list", w);
+        pg::WinDesc& W = wins[w];
+        W.n_hap = nh; W.n_ind = ni; W.n_reads = nr; W.n_gen = nh * (nh + 1) / 2;
+        W.like_base = like_base[w]; W.ioff_base = ioff; W.cell_base = cells; W.full_base = full;
+        W.hap_base = haps; W.ind_base = inds;
+        ioff += ni + 1; cells += (int64_t)ni * W.n_gen; full += (int64_t)ni * nh * nh; haps += nh; inds += ni;
+        max_h = std::max(max_h, nh); max_i = std::max(max_i, ni);
+    }
+    PG_HIP(c, hipSetDevice(c->device));
+    PG_HIP(c, c->d_wins.reserve((size_t)nw + 1)); PG_HIP(c, c->d_ioff.reserve((size_t)ioff + 1));
+    PG_HIP(c, c->d_cells.reserve((size_t)cells + 1)); PG_HIP(c, c->d_full.reserve((size_t)full + 1));
+    PG_HIP(c, c->d_freq.reserve((size_t)haps + 1)); PG_HIP(c, c->d_em_iters.reserve((size_t)nw + 1));
+    PG_HIP(c, c->d_em_change.reserve((size_t)nw + 1)); PG_HIP(c, c->d_best_gen.reserve((size_t)inds + 1));
+    PG_HIP(c, c->d_best_val.reserve((size_t)inds + 1));
+    if (nw > 0) {
+        PG_HIP(c, hipMemcpyAsync(c->d_wins.p, wins.data(), sizeof(pg::WinDesc) * nw, hipMemcpyHostToDevice, c->stream));
+        PG_HIP(c, hipMemcpyAsync(c->d_ioff.p, ind_read_off, sizeof(int32_t) * ioff, hipMemcpyHostToDevice, c->stream));
+        PG_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    c->h_wins.swap(wins);
+    c->n_windows = nw; c->max_win_haps = max_h; c->max_win_inds = max_i;
+    c->win_cells = cells; c->win_full = full; c->win_haps_total = haps; c->win_inds_total = inds;
+    return PG_OK;
+}
+
+int pg_caller_launch(pg_ctx* c, int max_iters) {
+    if (!c) return PG_ERR_INVALID;
+    if (!c->launched) return fail(c, PG_ERR_STATE, "no likelihoods on the device: launch an alignment first");
+    if (c->n_windows == 0) return fail(c, PG_ERR_STATE, "no windows uploaded");
+    for (const pg::WinDesc& W : c->h_wins)
+        if (W.like_base + (int64_t)W.n_hap * W.n_reads > c->n_pairs)
+            return fail(c, PG_ERR_STATE, "the windows do not fit the current pair list");
+    PG_HIP(c, hipSetDevice(c->device));
+    PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_CALLER_SETUP], c->stream));
+    hipLaunchKernelGGL(pg::k_gl, dim3((unsigned)((c->win_cells + 255) / 256)), dim3(256), 0, c->stream,
+                       c->d_wins.p, c->n_windows, c->d_ioff.p, c->d_like.p, c->d_cells.p, c->win_cells);
+    PG_HIP(c, hipGetLastError());
+    hipLaunchKernelGGL(pg::k_post_norm, dim3(c->n_windows), dim3(256), 0, c->stream,
+                       c->d_wins.p, c->d_ioff.p, c->d_cells.p, c->d_full.p);
+    PG_HIP(c, hipGetLastError());
+    PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_CALLER_SETUP + 1], c->stream));
+    c->ev_valid[PG_K_CALLER_SETUP] = true;
+    // one wavefront per individual, as many as the LDS rows allow: (3 + 2 W) n_max doubles
+    const int n_max = c->max_win_haps;
+    int n_wav = std::max(1, std::min(16, c->max_win_inds));
+    while (n_wav > 1 && (size_t)(3 + 2 * n_wav) * n_max * sizeof(double) > 150 * 1024) --n_wav;
+    const size_t lds = (size_t)(3 + 2 * n_wav) * n_max * sizeof(double);
+    PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_em), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_CALLER_EM], c->stream));
+    hipLaunchKernelGGL(pg::k_em, dim3(c->n_windows), dim3(64 * n_wav), lds, c->stream,
+                       c->d_wins.p, c->d_ioff.p, c->d_full.p, max_iters, n_max,
+                       c->d_freq.p, c->d_em_iters.p, c->d_em_change.p, c->d_best_gen.p, c->d_best_val.p);
+    PG_HIP(c, hipGetLastError());
+    PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_CALLER_EM + 1], c->stream));
+    c->ev_valid[PG_K_CALLER_EM] = true;
+    c->caller_done = true;
+    return PG_OK;
+}
+
+int pg_caller_fetch(pg_ctx* c, double* freq, int32_t* iters, double* max_change,
+                    int32_t* best_genotype, double* best_value, double* genotype_post) {
+    if (!c) return PG_ERR_INVALID;
+    if (!c->caller_done) return fail(c, PG_ERR_STATE, "pg_caller_fetch before pg_caller_launch");
+    PG_HIP(c, hipSetDevice(c->device));
+    if (freq) PG_HIP(c, hipMemcpyAsync(freq, c->d_freq.p, 8 * c->win_haps_total, hipMemcpyDeviceToHost, c->stream));
+    if (iters) PG_HIP(c, hipMemcpyAsync(iters, c->d_em_iters.p, 4 * (size_t)c->n_windows, hipMemcpyDeviceToHost, c->stream));
+    if (max_change) PG_HIP(c, hipMemcpyAsync(max_change, c->d_em_change.p, 8 * (size_t)c->n_windows, hipMemcpyDeviceToHost, c->stream));
+    if (best_genotype) PG_HIP(c, hipMemcpyAsync(best_genotype, c->d_best_gen.p, 4 * c->win_inds_total, hipMemcpyDeviceToHost, c->stream));
+    if (best_value) PG_HIP(c, hipMemcpyAsync(best_value, c->d_best_val.p, 8 * c->win_inds_total, hipMemcpyDeviceToHost, c->stream));
+    if (genotype_post) PG_HIP(c, hipMemcpyAsync(genotype_post, c->d_cells.p, 8 * c->win_cells, hipMemcpyDeviceToHost, c->stream));
+    PG_HIP(c, hipStreamSynchronize(c->stream));
+    return PG_OK;
+}
+
+int pg_variant_posteriors(pg_ctx* c, int nv, const int32_t* var_window, const uint8_t* hap_has_var,
+                          const double* prior, double* out) {
+    if (!c) return PG_ERR_INVALID;
+    if (nv < 0 || (nv > 0 && (!var_window || !hap_has_var || !prior || !out)))
+        return fail(c, PG_ERR_INVALID, "pg_variant_posteriors: bad arguments");
+    if (!c->caller_done) return fail(c, PG_ERR_STATE, "pg_variant_posteriors before pg_caller_launch");
+    if (nv == 0) return PG_OK;
+    std::vector<int64_t> moff((size_t)nv + 1, 0);
+    for (int v = 0; v < nv; ++v) {
+        if (var_window[v] < 0 || var_window[v] >= c->n_windows)
+            return fail(c, PG_ERR_INVALID, "variant %d names window %d of %d", v, var_window[v], c->n_windows);
+        moff[v + 1] = moff[v] + c->h_wins[var_window[v]].n_hap;
+    }
+    PG_HIP(c, hipSetDevice(c->device));
+    PG_HIP(c, c->d_var_win.reserve(nv)); PG_HIP(c, c->d_var_moff.reserve((size_t)nv + 1));
+    PG_HIP(c, c->d_var_mask.reserve((size_t)moff[nv] + 1)); PG_HIP(c, c->d_var_prior.reserve(nv));
+    PG_HIP(c, c->d_var_out.reserve(nv));
+    PG_HIP(c, hipMemcpyAsync(c->d_var_win.p, var_window, 4 * (size_t)nv, hipMemcpyHostToDevice, c->stream));
+    PG_HIP(c, hipMemcpyAsync(c->d_var_moff.p, moff.data(), 8 * ((size_t)nv + 1), hipMemcpyHostToDevice, c->stream));
+    PG_HIP(c, hipMemcpyAsync(c->d_var_mask.p, hap_has_var, (size_t)moff[nv], hipMemcpyHostToDevice, c->stream));
+    PG_HIP(c, hipMemcpyAsync(c->d_var_prior.p, prior, 8 * (size_t)nv, hipMemcpyHostToDevice, c->stream));
+    const size_t lds = (size_t)2 * c->max_win_haps * sizeof(double);
+    hipLaunchKernelGGL(pg::k_var_post, dim3(nv), dim3(64), lds, c->stream,
+                       c->d_wins.p, c->d_ioff.p, c->d_full.p, c->d_freq.p, c->d_var_win.p, c->d_var_moff.p,
+                       c->d_var_mask.p, c->d_var_prior.p, c->d_var_out.p, c->max_win_haps);
+    PG_HIP(c, hipGetLastError());
+    PG_HIP(c, hipMemcpyAsync(out, c->d_var_out.p, 8 * (size_t)nv, hipMemcpyDeviceToHost, c->stream));
+    PG_HIP(c, hipStreamSynchronize(c->stream));   // also keeps moff alive until the copies are done
     return PG_OK;
 }
 

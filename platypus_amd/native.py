@@ -15,8 +15,8 @@ LIB_PATH = os.environ.get("PLATGPU_LIB") or os.path.join(_HERE, "lib", "libplatg
 PG_OK = 0
 PG_ERR_NO_DEVICE, PG_ERR_INVALID, PG_ERR_HIP, PG_ERR_UNSUPPORTED, PG_ERR_STATE = -1, -2, -3, -4, -5
 PG_SCORE_ASSERT_FAILED = -1
-PG_K_ANCHOR, PG_K_ALIGN, PG_K_GENOTYPE = 0, 1, 2
-ABI_VERSION = 1
+PG_K_ANCHOR, PG_K_ALIGN, PG_K_GENOTYPE, PG_K_CALLER_SETUP, PG_K_CALLER_EM = 0, 1, 2, 3, 4
+ABI_VERSION = 2
 
 # every symbol include/platgpu.h declares: (restype, argtypes)
 _i32p, _i64p, _f64p = C.c_void_p, C.c_void_p, C.c_void_p
@@ -36,6 +36,10 @@ SYMBOLS = {
     "pg_align_pairs": (C.c_int, [C.c_void_p, C.c_int64, _i32p, _i32p, _i32p, _i32p, _f64p]),
     "pg_kernel_time_ms": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
     "pg_genotype_loglik": (C.c_int, [C.c_void_p, C.c_int64, _i64p, _i64p, _i32p, _f64p]),
+    "pg_windows_upload": (C.c_int, [C.c_void_p, C.c_int, _i32p, _i32p, _i64p, _i32p]),
+    "pg_caller_launch": (C.c_int, [C.c_void_p, C.c_int]),
+    "pg_caller_fetch": (C.c_int, [C.c_void_p, _f64p, _i32p, _f64p, _i32p, _f64p, _f64p]),
+    "pg_variant_posteriors": (C.c_int, [C.c_void_p, C.c_int, _i32p, C.c_void_p, _f64p, _f64p]),
     "pg_valu_int16_peak": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
 }
 
@@ -162,4 +166,39 @@ class AlignContext(object):
         b1 = _arr(base1, np.int64); b2 = _arr(base2, np.int64); nr = _arr(n_reads, np.int32)
         out = np.empty(len(b1), dtype=np.float64)
         self._check(LIB.pg_genotype_loglik(self._h, len(b1), _ptr(b1), _ptr(b2), _ptr(nr), _ptr(out)))
+        return out
+
+    # ---- genotype likelihoods, EM, variant posteriors over windows ----
+
+    def upload_windows(self, n_haps, n_inds, like_base, ind_read_off):
+        nh = _arr(n_haps, np.int32); ni = _arr(n_inds, np.int32)
+        lb = _arr(like_base, np.int64); io = _arr(ind_read_off, np.int32)
+        assert len(nh) == len(ni) == len(lb) and len(io) == int(ni.sum()) + len(ni)
+        self._check(LIB.pg_windows_upload(self._h, len(nh), _ptr(nh), _ptr(ni), _ptr(lb), _ptr(io)))
+        self._win = (nh.copy(), ni.copy())
+
+    def caller_launch(self, max_iters=100):
+        self._check(LIB.pg_caller_launch(self._h, max_iters))
+
+    def caller_fetch(self, genotype_post=True):
+        """dict of flat arrays (see include/platgpu.h: pg_caller_fetch) plus the offsets to slice them."""
+        nh, ni = self._win
+        ng = nh.astype(np.int64) * (nh + 1) // 2
+        hap_off = np.concatenate([[0], np.cumsum(nh, dtype=np.int64)])
+        ind_off = np.concatenate([[0], np.cumsum(ni, dtype=np.int64)])
+        cell_off = np.concatenate([[0], np.cumsum(ni * ng, dtype=np.int64)])
+        freq = np.empty(int(hap_off[-1]), dtype=np.float64)
+        iters = np.empty(len(nh), dtype=np.int32)
+        change = np.empty(len(nh), dtype=np.float64)
+        best = np.empty(int(ind_off[-1]), dtype=np.int32)
+        val = np.empty(int(ind_off[-1]), dtype=np.float64)
+        post = np.empty(int(cell_off[-1]), dtype=np.float64) if genotype_post else None
+        self._check(LIB.pg_caller_fetch(self._h, _ptr(freq), _ptr(iters), _ptr(change), _ptr(best), _ptr(val), _ptr(post)))
+        return dict(freq=freq, iters=iters, max_change=change, best_gen=best, best_val=val, post=post,
+                    hap_off=hap_off, ind_off=ind_off, cell_off=cell_off, n_gen=ng)
+
+    def variant_posteriors(self, var_window, hap_has_var, prior):
+        vw = _arr(var_window, np.int32); m = _arr(hap_has_var, np.uint8); pr = _arr(prior, np.float64)
+        out = np.empty(len(vw), dtype=np.float64)
+        self._check(LIB.pg_variant_posteriors(self._h, len(vw), _ptr(vw), _ptr(m), _ptr(pr), _ptr(out)))
         return out

@@ -1,0 +1,113 @@
+"""GPU parity of the genotype-likelihood / EM / variant-posterior stage (through the C ABI)
+against the CPU restatement of platypus/cpopulation.pyx:515-632,658-890.
+
+Tolerance: 1e-9 relative on every double (the device's log/exp differ from libm in the last
+bits and sums over genotypes are regrouped); iteration counts and genotype calls must be equal
+(a call may differ only where the checker's own csr values tie to 1e-12)."""
+import numpy as np
+import pytest
+
+from platypus_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-9
+
+
+def split_reads(rng, n_reads, n_ind, empty=None):
+    """ascending offsets 0..n_reads for n_ind individuals; individual `empty` gets no reads"""
+    cuts = np.sort(rng.integers(1, n_reads, size=n_ind - 1)) if n_ind > 1 else np.empty(0, dtype=np.int64)
+    off = np.concatenate([[0], cuts, [n_reads]]).astype(np.int32)
+    if empty is not None and n_ind > 1:
+        off[empty + 1] = off[empty]
+        off = np.maximum.accumulate(off)
+        off[-1] = n_reads
+    return off
+
+
+def run_case(n_windows, H, R, n_ind, seed, indel_frac=0.3, empty=None, read_len=60, hap_len=300):
+    from platypus_amd import native
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(seed)
+    b = synth.make_batch(n_windows=n_windows, haps_per_window=H, reads_per_window=R, read_len=read_len,
+                         hap_len=hap_len, indel_hap_frac=indel_frac, seed=seed)
+    ctx = native.AlignContext(0)
+    try:
+        ctx.upload_batch(b)
+        ctx.launch()
+        offs = [split_reads(rng, R, n_ind, empty if (w % 3 == 0) else None) for w in range(n_windows)]
+        ctx.upload_windows([H] * n_windows, [n_ind] * n_windows,
+                           np.arange(n_windows, dtype=np.int64) * H * R, np.concatenate(offs))
+        ctx.caller_launch(100)
+        res = ctx.caller_fetch()
+        _, _, like = ctx.fetch()
+        n_gen = H * (H + 1) // 2
+        # variants: haplotype h > 0 carries "its" variant; plus one variant shared by two haplotypes
+        var_win, masks, priors = [], [], []
+        for w in range(n_windows):
+            for h in range(1, H):
+                m = np.zeros(H, dtype=np.uint8); m[h] = 1
+                if h == 1 and H > 2:
+                    m[2] = 1
+                var_win.append(w); masks.append(m); priors.append(10.0 ** -rng.integers(1, 5))
+        gpu_vp = ctx.variant_posteriors(var_win, np.concatenate(masks), priors)
+    finally:
+        ctx.close()
+
+    vi = 0
+    for w in range(n_windows):
+        L = like[w * H * R:(w + 1) * H * R].reshape(H, R)
+        post = po.caller_setup(L, offs[w])
+        g_post = res["post"][res["cell_off"][w]:res["cell_off"][w + 1]].reshape(n_ind, n_gen)
+        np.testing.assert_allclose(g_post, post, rtol=RTOL, atol=0)
+        ref = po.caller_call(post, offs[w], H, want_cisr=True)
+        assert res["iters"][w] == ref["iters"], (w, res["iters"][w], ref["iters"])
+        g_freq = res["freq"][res["hap_off"][w]:res["hap_off"][w + 1]]
+        np.testing.assert_allclose(g_freq, ref["freq"], rtol=RTOL, atol=1e-300)
+        np.testing.assert_allclose(res["max_change"][w], ref["max_change"], rtol=1e-6, atol=1e-15)
+        g_best = res["best_gen"][res["ind_off"][w]:res["ind_off"][w + 1]]
+        g_val = res["best_val"][res["ind_off"][w]:res["ind_off"][w + 1]]
+        np.testing.assert_allclose(g_val, ref["best_val"], rtol=RTOL, atol=1e-300)
+        for i in range(n_ind):
+            if g_best[i] != ref["best_gen"][i]:
+                c = ref["cisr"][i]
+                assert g_best[i] >= 0 and abs(c[g_best[i]] - c[ref["best_gen"][i]]) <= 1e-12 * abs(c[ref["best_gen"][i]])
+        for h in range(1, H):
+            want = po.variant_posterior(post, offs[w], ref["freq"], masks[vi], priors[vi])
+            np.testing.assert_allclose(gpu_vp[vi], want, rtol=1e-8, atol=1e-300)
+            vi += 1
+
+
+def test_single_sample_windows():
+    run_case(n_windows=96, H=4, R=32, n_ind=1, seed=11)
+
+
+def test_few_individuals_with_an_empty_one():
+    run_case(n_windows=24, H=6, R=60, n_ind=4, seed=12, empty=1)
+
+
+def test_many_haplotypes_many_individuals():
+    run_case(n_windows=3, H=70, R=240, n_ind=20, seed=13, indel_frac=0.2)
+
+
+def test_two_haplotypes():
+    run_case(n_windows=40, H=2, R=16, n_ind=2, seed=14)
+
+
+def test_window_errors():
+    from platypus_amd import native
+    b = synth.make_batch(n_windows=2, haps_per_window=3, reads_per_window=8, read_len=40, hap_len=200, seed=5)
+    ctx = native.AlignContext(0)
+    try:
+        ctx.upload_batch(b)
+        with pytest.raises(native.PlatGpuError):          # no alignment launched yet
+            ctx.upload_windows([3, 3], [1, 1], [0, 24], [0, 8, 0, 8]); ctx.caller_launch()
+        ctx.launch()
+        with pytest.raises(native.PlatGpuError):          # reaches outside the pair list
+            ctx.upload_windows([3, 3], [1, 1], [0, 30], [0, 8, 0, 8])
+        with pytest.raises(native.PlatGpuError):          # no reads at all
+            ctx.upload_windows([3], [2], [0], [0, 0, 0])
+        with pytest.raises(native.PlatGpuError):          # offsets must ascend
+            ctx.upload_windows([3], [2], [0], [0, 9, 8])
+    finally:
+        ctx.close()
