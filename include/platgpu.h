@@ -152,6 +152,15 @@ int pg_genotype_loglik(pg_ctx *ctx, int64_t n_gen, const int64_t *pair_base1,
                        const int64_t *pair_base2, const int32_t *n_reads, double *out);
 
 /*
+ * The same sum for one genotype whose two likelihood rows are on the host
+ * (the rows Haplotype.alignReads returned, platypus/cgenotype.pyx:55-56): the
+ * rows are copied to the device and summed there.  The per-call form of
+ * DiploidGenotype.calculateDataLikelihood; slow, use the batched entry points
+ * where the caller can.
+ */
+int pg_genotype_loglik_rows(pg_ctx *ctx, int n_reads, const double *row1, const double *row2, double *out);
+
+/*
  * ---- The stage that consumes the likelihood matrix: Caller.setup / Caller.call /
  * ---- Population.calculatePosterior of platypus/cpopulation.pyx, batched over windows.
  *

@@ -1,4 +1,4 @@
-"""Build the Cython 3 layer (calign, cwindow, chaplotype, cgenotype) in-tree.
+"""Build the Cython 3 layer (calign, cwindow, chaplotype, cgenotype, cpopulation) in-tree.
 
     python -m platypus_amd.build_cython [--force]
 
@@ -11,8 +11,8 @@ import sysconfig
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-MODULES = ["calign", "cwindow", "chaplotype", "cgenotype"]
-PXD = ["samtoolsWrapper.pxd", "platgpu.pxd", "calign.pxd", "cwindow.pxd", "chaplotype.pxd", "cgenotype.pxd"]
+MODULES = ["calign", "cwindow", "chaplotype", "cgenotype", "cpopulation"]
+PXD = ["samtoolsWrapper.pxd", "platgpu.pxd", "calign.pxd", "cwindow.pxd", "chaplotype.pxd", "cgenotype.pxd", "cpopulation.pxd"]
 
 
 def _ext_path(mod):

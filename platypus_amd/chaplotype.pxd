@@ -25,4 +25,4 @@ cdef class Haplotype:
             int nIndividuals
     ) except NULL
 
-cdef int prefetchWindowC(list haplotypes, list readBuffers) except -1
+cdef int prefetchWindowC(list haplotypes, list readBuffers, bint always=*) except -1

@@ -104,14 +104,20 @@ cdef class Haplotype:
     def isCached(self, int individualIndex):
         return self.lenCache > individualIndex and self.likesByIndCache[individualIndex] != NULL
 
+    def variantsPy(self):
+        return self.variants
+
     property sequence:
         def __get__(self):
             return self.haplotypeSequence
 
 
-cdef int prefetchWindowC(list haplotypes, list readBuffers) except -1:
+cdef int prefetchWindowC(list haplotypes, list readBuffers, bint always=False) except -1:
     """Score all haplotypes x all individuals' window reads in one launch and fill
-    every likesByIndCache entry that is still empty."""
+    every likesByIndCache entry that is still empty.  After the call the window's
+    likelihood matrix is resident on the device, haplotype-major, reads in the order
+    of the individuals (what the genotype / EM kernels take).  Without `always` the
+    launch is skipped when every cache is already filled."""
     cdef int nH = len(haplotypes), nI = len(readBuffers)
     cdef int h, i, r, nTot = 0, n
     cdef Haplotype hap
@@ -141,10 +147,21 @@ cdef int prefetchWindowC(list haplotypes, list readBuffers) except -1:
             starts[h] = hap.startPos
             vls[h] = hap.varSeqLen
             lens[h] = hap.hapLen
-        if nTot > 0:
+        if not always:
+            always = False
+            for h in range(nH):
+                hap = haplotypes[h]
+                if hap.lenCache < nI:
+                    always = True
+                    break
+                for i in range(nI):
+                    if hap.likesByIndCache[i] == NULL:
+                        always = True
+                        break
+        if nTot > 0 and always:
             hap = haplotypes[0]
             alignBatch(nH, seqs, starts, vls, lens, reads, reads + nTot, hap.cHomopolQ, 3, 2, like, NULL, NULL)
-        for h in range(nH):
+        for h in range(nH if always else 0):
             hap = haplotypes[h]
             hap.ensureCache(nI)
             base = 0

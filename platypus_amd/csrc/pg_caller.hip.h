@@ -8,9 +8,9 @@
 // [ioff[i], ioff[i+1]).  Genotypes are the pairs (a <= b) in the order of
 // platypus/cgenotype.pyx:90-96; packed index of (a, b): a n - a (a - 1) / 2 + b - a.
 //
-//   k_gl          log-likelihood of every (individual, genotype)
-//   k_post_norm   one maximum per window, exp(ll - max); also written as full
-//                 symmetric n x n matrices, the layout the EM streams
+//   k_gl          log-likelihood of every (individual, genotype), maximum per window
+//   k_norm        exp(ll - maximum of the window); also written as full symmetric
+//                 n x n matrices, the layout the EM streams
 //   k_em          EM iterations and genotype calls, one workgroup per window
 //   k_var_post    posterior of a variant given the haplotypes that carry it
 //
@@ -56,25 +56,52 @@ __device__ __forceinline__ double wave_max(double v) {
     return v;
 }
 
-// ---------------------------------------------------------------------------
-// k_gl: ll[cell] = sum over the individual's reads, in read order, of
-// log(0.5 (L[a][r] + L[b][r]))  (platypus/cgenotype.pyx:58-61).  One thread per
-// (window, individual, genotype) cell; an individual without reads keeps 0.0
-// (platypus/cpopulation.pyx:717-718).
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_gl(const WinDesc* __restrict__ wins, int n_win,
-                                            const int32_t* __restrict__ ioff,
-                                            const double* __restrict__ like,
-                                            double* __restrict__ ll, int64_t n_cells)
-{
-    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (c >= n_cells) return;
+// Order-preserving map of a double onto an unsigned 64-bit integer, so that the
+// maximum of doubles can be taken with an integer atomic (any order, same result).
+__device__ __forceinline__ unsigned long long ordered_bits(double v) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double from_ordered_bits(unsigned long long k) {
+    const unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)u);
+}
+
+__device__ __forceinline__ int window_of_cell(const WinDesc* __restrict__ wins, int n_win, int64_t c) {
     int lo = 0, hi = n_win - 1;                      // last window with cell_base <= c
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
         if (wins[mid].cell_base <= c) lo = mid; else hi = mid - 1;
     }
-    const WinDesc W = wins[lo];
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void k_fill_u64(unsigned long long* __restrict__ dst, int n, double v)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = ordered_bits(v);
+}
+
+// ---------------------------------------------------------------------------
+// k_gl: ll[cell] = sum over the individual's reads, in read order, of
+// log(0.5 (L[a][r] + L[b][r]))  (platypus/cgenotype.pyx:58-61).  One thread per
+// (window, individual, genotype) cell; an individual without reads keeps 0.0
+// and stays out of the window's maximum (platypus/cpopulation.pyx:717-723).
+// win_max[w] must hold ordered_bits(-1e7) on entry (platypus/cpopulation.pyx:696).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gl(const WinDesc* __restrict__ wins, int n_win,
+                                            const int32_t* __restrict__ ioff,
+                                            const double* __restrict__ like,
+                                            double* __restrict__ ll, unsigned long long* __restrict__ win_max,
+                                            int64_t n_cells)
+{
+    // threads past the end redo the last cell (no stores), so that every lane of a wavefront
+    // takes part in the cross-lane maximum below
+    const int64_t c_raw = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = c_raw < n_cells;
+    const int64_t c = valid ? c_raw : n_cells - 1;
+    const int w = window_of_cell(wins, n_win, c);
+    const WinDesc W = wins[w];
     const int64_t rem = c - W.cell_base;
     const int i = (int)(rem / W.n_gen), g = (int)(rem % W.n_gen);
     const int a = tri_row_of(g, W.n_hap), b = a + (int)(g - tri_row_start(a, W.n_hap));
@@ -83,41 +110,40 @@ __global__ __launch_bounds__(256) void k_gl(const WinDesc* __restrict__ wins, in
     const double* l2 = like + W.like_base + (int64_t)b * W.n_reads + r0;
     double s = 0.0;
     for (int r = 0; r < nr; ++r) s += log(0.5 * (l1[r] + l2[r]));
-    ll[c] = s;
+    if (valid) ll[c] = s;
+    // one atomic per wavefront when all its cells belong to one window, else one per cell
+    const int w0 = __builtin_amdgcn_readfirstlane(w);
+    if (__all(w == w0)) {
+        const double m = wave_max(nr > 0 ? s : -1e7);
+        if ((threadIdx.x & 63) == 0) atomicMax(&win_max[w0], ordered_bits(m));
+    } else if (nr > 0) {
+        atomicMax(&win_max[w], ordered_bits(s));
+    }
 }
 
 // ---------------------------------------------------------------------------
-// k_post_norm: platypus/cpopulation.pyx:696,722-734.  One workgroup per window:
-// maximum log-likelihood over the cells of individuals with reads (start value
-// -1e7), then post = exp(ll - max) for every cell, in place, and mirrored into
-// the full matrices full[i][a][b] = full[i][b][a].
+// k_norm: platypus/cpopulation.pyx:732-734.  post = exp(ll - max of the window)
+// for every cell, in place, and mirrored into the full matrices
+// full[i][a][b] = full[i][b][a].  One thread per cell.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_post_norm(const WinDesc* __restrict__ wins,
-                                                   const int32_t* __restrict__ ioff,
-                                                   double* __restrict__ cells, double* __restrict__ full)
+__global__ __launch_bounds__(256) void k_norm(const WinDesc* __restrict__ wins, int n_win,
+                                              const unsigned long long* __restrict__ win_max,
+                                              double* __restrict__ cells, double* __restrict__ full,
+                                              int64_t n_cells)
 {
-    __shared__ double s_red[4];
-    const WinDesc W = wins[blockIdx.x];
-    const int tid = threadIdx.x, n = W.n_hap;
-    const int64_t total = (int64_t)W.n_ind * W.n_gen;
-    double mx = -1e7;
-    for (int64_t k = tid; k < total; k += 256) {
-        const int i = (int)(k / W.n_gen);
-        if (ioff[W.ioff_base + i + 1] != ioff[W.ioff_base + i]) mx = fmax(mx, cells[W.cell_base + k]);
-    }
-    mx = wave_max(mx);
-    if ((tid & 63) == 0) s_red[tid >> 6] = mx;
-    __syncthreads();
-    mx = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
-    for (int64_t k = tid; k < total; k += 256) {
-        const int i = (int)(k / W.n_gen), g = (int)(k % W.n_gen);
-        const double p = exp(cells[W.cell_base + k] - mx);
-        cells[W.cell_base + k] = p;
-        const int a = tri_row_of(g, n), b = a + (int)(g - tri_row_start(a, n));
-        double* F = full + W.full_base + (int64_t)i * n * n;
-        F[(int64_t)a * n + b] = p;
-        F[(int64_t)b * n + a] = p;
-    }
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= n_cells) return;
+    const int w = window_of_cell(wins, n_win, c);
+    const WinDesc W = wins[w];
+    const int n = W.n_hap;
+    const int64_t rem = c - W.cell_base;
+    const int i = (int)(rem / W.n_gen), g = (int)(rem % W.n_gen);
+    const double p = exp(cells[c] - from_ordered_bits(win_max[w]));
+    cells[c] = p;
+    const int a = tri_row_of(g, n), b = a + (int)(g - tri_row_start(a, n));
+    double* F = full + W.full_base + (int64_t)i * n * n;
+    F[(int64_t)a * n + b] = p;
+    F[(int64_t)b * n + a] = p;
 }
 
 // ---------------------------------------------------------------------------
@@ -135,19 +161,60 @@ __global__ __launch_bounds__(256) void k_post_norm(const WinDesc* __restrict__ w
 //
 // The genotype calls (:773-797) use the csr values of the LAST iteration, i.e.
 // the frequencies before its update; they are recomputed from those at the end.
-// LDS: f, f_prev, f_new [n_max] | per wavefront: y [n_max], acc [n_max].
+// LDS: f, f_prev, f_new [n_max] | per wavefront: y [n_max], acc [n_max] | staged matrices
+// (stage_doubles > 0: every window of the batch has at most that many matrix elements).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_em(const WinDesc* __restrict__ wins,
-                                             const int32_t* __restrict__ ioff,
-                                             const double* __restrict__ full,
-                                             int max_iters, int n_max,
-                                             double* __restrict__ freq_out, int32_t* __restrict__ iters_out,
-                                             double* __restrict__ change_out, int32_t* __restrict__ best_gen,
-                                             double* __restrict__ best_val)
+// Columns k0 + c * 64 + lane, c < NC, of y = P f for one wavefront: yv[k] = y_k, returns the
+// lane's share of f . y.  16 independent loads are in flight per lane (NC column chunks x
+// 16 / NC rows, all loads of a group issued before its sums); every y_k is still summed over
+// the rows in row order.
+template <int NC>
+__device__ __forceinline__ double matvec_pass(const double* P, const double* f_src, double* yv,
+                                              int n, int k0, int lane)
 {
-    extern __shared__ double em_lds[];
-    __shared__ double s_red[16];
-    __shared__ int s_with_data;
+    constexpr int RU = 16 / NC;
+    double y[NC];
+    int kk[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { const int k = k0 + c * 64 + lane; kk[c] = k < n ? k : n - 1; y[c] = 0.0; }
+    int r = 0;
+    for (; r + RU <= n; r += RU) {
+        double pv[RU][NC];
+#pragma unroll
+        for (int u = 0; u < RU; ++u)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) pv[u][c] = P[(int64_t)(r + u) * n + kk[c]];
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const double fr = f_src[r + u];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) y[c] += pv[u][c] * fr;
+        }
+    }
+    for (; r < n; ++r) {
+        const double fr = f_src[r];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) y[c] += P[(int64_t)r * n + kk[c]] * fr;
+    }
+    double part = 0.0;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int k = k0 + c * 64 + lane;
+        if (k < n) { yv[k] = y[c]; part += f_src[k] * y[c]; }
+    }
+    return part;
+}
+
+template <bool STAGED>
+__device__ __forceinline__ void em_window(double* em_lds, double* s_red, int* s_with_data_p,
+                                          const WinDesc* __restrict__ wins,
+                                          const int32_t* __restrict__ ioff,
+                                          const double* __restrict__ full,
+                                          int max_iters, int n_max,
+                                          double* __restrict__ freq_out, int32_t* __restrict__ iters_out,
+                                          double* __restrict__ change_out, int32_t* __restrict__ best_gen,
+                                          double* __restrict__ best_val)
+{
     const WinDesc W = wins[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_thr = blockDim.x, n_wav = n_thr >> 6;
@@ -159,31 +226,41 @@ __global__ __launch_bounds__(1024) void k_em(const WinDesc* __restrict__ wins,
     double* acc = yv + n_max;
     const int32_t* io = ioff + W.ioff_base;
 
+    // STAGED: the window's matrices are copied to LDS once and every iteration reads them there.
+    // The two cases are separate instantiations so that each pointer keeps its address space
+    // (one pointer that may be either becomes a flat pointer, and every flat load waits for
+    // all memory counters: the loads of the product below would run one at a time).
+    double* const stage = em_lds + (size_t)(3 + 2 * n_wav) * n_max;
+    const double* const P_glob = full + W.full_base;
+    if (STAGED) {
+        const int tot = W.n_ind * n * n;
+        for (int k = tid; k < tot; k += n_thr) stage[k] = P_glob[k];
+    }
+
     if (tid == 0) {
         int c = 0;
         for (int i = 0; i < W.n_ind; ++i) c += io[i + 1] != io[i];
-        s_with_data = c;
+        *s_with_data_p = c;
     }
     for (int k = tid; k < n; k += n_thr) f[k] = 1.0 / n;                    // :753,763-764
     __syncthreads();
-    const int n_with_data = s_with_data;
+    const int n_with_data = *s_with_data_p;
     double eps = 1.0 / (W.n_ind * 2 * 2);                                    // :751
     eps = eps < 1e-3 ? eps : 1e-3;
     double max_change = eps + 1;
     int iters = 0;
 
-    // y = P_i f_src and csrSum = f_src . y for individual i, by this wavefront
+    // y = P_i f_src and csrSum = f_src . y for individual i, by this wavefront: 256 columns
+    // per pass, 64 per lane group (see matvec_pass).
     auto matvec = [&](int i, const double* f_src) -> double {
-        const double* P = full + W.full_base + (int64_t)i * n * n;
+        const double* P = (STAGED ? (const double*)stage : P_glob) + (int64_t)i * n * n;
         double part = 0.0;
-        for (int k0 = 0; k0 < n; k0 += 64) {
-            const int k = k0 + lane;
-            double y = 0.0;
-            if (k < n) {
-                for (int r = 0; r < n; ++r) y += P[(int64_t)r * n + k] * f_src[r];
-                yv[k] = y;
-                part += f_src[k] * y;
-            }
+        for (int k0 = 0; k0 < n; k0 += 256) {
+            const int nc = (n - k0 + 63) >> 6;
+            if (nc >= 4)      part += matvec_pass<4>(P, f_src, yv, n, k0, lane);
+            else if (nc == 3) part += matvec_pass<3>(P, f_src, yv, n, k0, lane);
+            else if (nc == 2) part += matvec_pass<2>(P, f_src, yv, n, k0, lane);
+            else              part += matvec_pass<1>(P, f_src, yv, n, k0, lane);
         }
         return wave_sum(part);
     };
@@ -232,7 +309,7 @@ __global__ __launch_bounds__(1024) void k_em(const WinDesc* __restrict__ wins,
             continue;
         }
         const double s = matvec(i, f_prev);
-        const double* P = full + W.full_base + (int64_t)i * n * n;
+        const double* P = (STAGED ? (const double*)stage : P_glob) + (int64_t)i * n * n;
         double bv = 0.0;
         int bj = 0x7fffffff;
         for (int a = 0; a < n; ++a) {
@@ -252,6 +329,25 @@ __global__ __launch_bounds__(1024) void k_em(const WinDesc* __restrict__ wins,
         }
         if (lane == 0) { best_gen[W.ind_base + i] = bj; best_val[W.ind_base + i] = bv; }
     }
+}
+
+__global__ __launch_bounds__(1024) void k_em(const WinDesc* __restrict__ wins,
+                                             const int32_t* __restrict__ ioff,
+                                             const double* __restrict__ full,
+                                             int max_iters, int n_max, int staged,
+                                             double* __restrict__ freq_out, int32_t* __restrict__ iters_out,
+                                             double* __restrict__ change_out, int32_t* __restrict__ best_gen,
+                                             double* __restrict__ best_val)
+{
+    extern __shared__ double em_lds[];
+    __shared__ double s_red[16];
+    __shared__ int s_with_data;
+    if (staged)
+        em_window<true>(em_lds, s_red, &s_with_data, wins, ioff, full, max_iters, n_max,
+                        freq_out, iters_out, change_out, best_gen, best_val);
+    else
+        em_window<false>(em_lds, s_red, &s_with_data, wins, ioff, full, max_iters, n_max,
+                         freq_out, iters_out, change_out, best_gen, best_val);
 }
 
 // ---------------------------------------------------------------------------

@@ -95,6 +95,7 @@ struct pg_ctx {
 
     // windows of the genotype / EM stage
     int n_windows = 0, max_win_haps = 0, max_win_inds = 0;
+    int64_t max_win_full = 0;             // largest n_ind * n_hap^2 of a window
     int64_t win_cells = 0, win_full = 0, win_haps_total = 0, win_inds_total = 0;
     bool caller_done = false;
     std::vector<pg::WinDesc> h_wins;
@@ -102,12 +103,13 @@ struct pg_ctx {
     DevBuf<int32_t> d_ioff, d_em_iters, d_best_gen, d_var_win;
     DevBuf<double> d_cells, d_full, d_freq, d_em_change, d_best_val, d_var_prior, d_var_out;
     DevBuf<int64_t> d_var_moff;
+    DevBuf<unsigned long long> d_win_max;
     DevBuf<uint8_t> d_var_mask;
 
     // genotype scratch
     DevBuf<int64_t> d_g1, d_g2;
     DevBuf<int32_t> d_gn;
-    DevBuf<double> d_gout;
+    DevBuf<double> d_gout, d_rows;
 };
 
 namespace {
@@ -213,7 +215,7 @@ int pg_ctx_destroy(pg_ctx* c) {
     c->d_vh_list.release(); c->d_anchor_in.release(); c->d_vh_ptr.release();
     c->d_n_flag.release(); c->d_wins.release(); c->d_ioff.release(); c->d_em_iters.release(); c->d_best_gen.release();
     c->d_var_win.release(); c->d_cells.release(); c->d_full.release(); c->d_freq.release(); c->d_em_change.release();
-    c->d_best_val.release(); c->d_var_prior.release(); c->d_var_out.release(); c->d_var_moff.release(); c->d_var_mask.release(); c->d_vh_recs.release(); c->d_waves.release(); c->d_score.release(); c->d_anchor.release(); c->d_like.release();
+    c->d_best_val.release(); c->d_var_prior.release(); c->d_var_out.release(); c->d_var_moff.release(); c->d_win_max.release(); c->d_rows.release(); c->d_var_mask.release(); c->d_vh_recs.release(); c->d_waves.release(); c->d_score.release(); c->d_anchor.release(); c->d_like.release();
     c->d_g1.release(); c->d_g2.release(); c->d_gn.release(); c->d_gout.release();
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -591,6 +593,31 @@ int pg_genotype_loglik(pg_ctx* c, int64_t ng, const int64_t* b1, const int64_t* 
     return PG_OK;
 }
 
+int pg_genotype_loglik_rows(pg_ctx* c, int n, const double* row1, const double* row2, double* out) {
+    if (!c) return PG_ERR_INVALID;
+    if (n < 0 || !out || (n > 0 && (!row1 || !row2)))
+        return fail(c, PG_ERR_INVALID, "pg_genotype_loglik_rows: bad arguments");
+    PG_HIP(c, hipSetDevice(c->device));
+    PG_HIP(c, c->d_rows.reserve((size_t)2 * n + 2));
+    PG_HIP(c, c->d_g1.reserve(1)); PG_HIP(c, c->d_g2.reserve(1));
+    PG_HIP(c, c->d_gn.reserve(1)); PG_HIP(c, c->d_gout.reserve(1));
+    const int64_t b1 = 0, b2 = n;
+    const int32_t nr = n;
+    if (n > 0) {
+        PG_HIP(c, hipMemcpyAsync(c->d_rows.p, row1, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+        PG_HIP(c, hipMemcpyAsync(c->d_rows.p + n, row2, 8 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    }
+    PG_HIP(c, hipMemcpyAsync(c->d_g1.p, &b1, 8, hipMemcpyHostToDevice, c->stream));
+    PG_HIP(c, hipMemcpyAsync(c->d_g2.p, &b2, 8, hipMemcpyHostToDevice, c->stream));
+    PG_HIP(c, hipMemcpyAsync(c->d_gn.p, &nr, 4, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(pg::k_genotype, dim3(1), dim3(256), 0, c->stream,
+                       c->d_rows.p, c->d_g1.p, c->d_g2.p, c->d_gn.p, c->d_gout.p, (int64_t)1);
+    PG_HIP(c, hipGetLastError());
+    PG_HIP(c, hipMemcpyAsync(out, c->d_gout.p, 8, hipMemcpyDeviceToHost, c->stream));
+    PG_HIP(c, hipStreamSynchronize(c->stream));   // b1, b2, nr live until here
+    return PG_OK;
+}
+
 int pg_windows_upload(pg_ctx* c, int nw, const int32_t* n_haps, const int32_t* n_inds,
                       const int64_t* like_base, const int32_t* ind_read_off) {
     if (!c) return PG_ERR_INVALID;
@@ -600,6 +627,7 @@ int pg_windows_upload(pg_ctx* c, int nw, const int32_t* n_haps, const int32_t* n
     std::vector<pg::WinDesc> wins((size_t)nw);
     int64_t ioff = 0, cells = 0, full = 0, haps = 0, inds = 0;
     int max_h = 0, max_i = 0;
+    int64_t max_full = 0;
     for (int w = 0; w < nw; ++w) {
         const int nh = n_haps[w], ni = n_inds[w];
         if (nh < 1 || nh > 1000)
@@ -620,6 +648,7 @@ int pg_windows_upload(pg_ctx* c, int nw, const int32_t* n_haps, const int32_t* n
         W.hap_base = haps; W.ind_base = inds;
         ioff += ni + 1; cells += (int64_t)ni * W.n_gen; full += (int64_t)ni * nh * nh; haps += nh; inds += ni;
         max_h = std::max(max_h, nh); max_i = std::max(max_i, ni);
+        max_full = std::max(max_full, (int64_t)ni * nh * nh);
     }
     PG_HIP(c, hipSetDevice(c->device));
     PG_HIP(c, c->d_wins.reserve((size_t)nw + 1)); PG_HIP(c, c->d_ioff.reserve((size_t)ioff + 1));
@@ -633,7 +662,7 @@ int pg_windows_upload(pg_ctx* c, int nw, const int32_t* n_haps, const int32_t* n
         PG_HIP(c, hipStreamSynchronize(c->stream));
     }
     c->h_wins.swap(wins);
-    c->n_windows = nw; c->max_win_haps = max_h; c->max_win_inds = max_i;
+    c->n_windows = nw; c->max_win_haps = max_h; c->max_win_inds = max_i; c->max_win_full = max_full;
     c->win_cells = cells; c->win_full = full; c->win_haps_total = haps; c->win_inds_total = inds;
     return PG_OK;
 }
@@ -647,11 +676,14 @@ int pg_caller_launch(pg_ctx* c, int max_iters) {
             return fail(c, PG_ERR_STATE, "the windows do not fit the current pair list");
     PG_HIP(c, hipSetDevice(c->device));
     PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_CALLER_SETUP], c->stream));
+    PG_HIP(c, c->d_win_max.reserve((size_t)c->n_windows));
+    hipLaunchKernelGGL(pg::k_fill_u64, dim3((c->n_windows + 255) / 256), dim3(256), 0, c->stream,
+                       c->d_win_max.p, c->n_windows, -1e7);
     hipLaunchKernelGGL(pg::k_gl, dim3((unsigned)((c->win_cells + 255) / 256)), dim3(256), 0, c->stream,
-                       c->d_wins.p, c->n_windows, c->d_ioff.p, c->d_like.p, c->d_cells.p, c->win_cells);
+                       c->d_wins.p, c->n_windows, c->d_ioff.p, c->d_like.p, c->d_cells.p, c->d_win_max.p, c->win_cells);
     PG_HIP(c, hipGetLastError());
-    hipLaunchKernelGGL(pg::k_post_norm, dim3(c->n_windows), dim3(256), 0, c->stream,
-                       c->d_wins.p, c->d_ioff.p, c->d_cells.p, c->d_full.p);
+    hipLaunchKernelGGL(pg::k_norm, dim3((unsigned)((c->win_cells + 255) / 256)), dim3(256), 0, c->stream,
+                       c->d_wins.p, c->n_windows, c->d_win_max.p, c->d_cells.p, c->d_full.p, c->win_cells);
     PG_HIP(c, hipGetLastError());
     PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_CALLER_SETUP + 1], c->stream));
     c->ev_valid[PG_K_CALLER_SETUP] = true;
@@ -659,11 +691,14 @@ int pg_caller_launch(pg_ctx* c, int max_iters) {
     const int n_max = c->max_win_haps;
     int n_wav = std::max(1, std::min(16, c->max_win_inds));
     while (n_wav > 1 && (size_t)(3 + 2 * n_wav) * n_max * sizeof(double) > 150 * 1024) --n_wav;
-    const size_t lds = (size_t)(3 + 2 * n_wav) * n_max * sizeof(double);
+    size_t lds = (size_t)(3 + 2 * n_wav) * n_max * sizeof(double);
+    // windows whose matrices all fit in 32 KiB keep them in LDS
+    int stage = 0;
+    if (c->max_win_full <= 4096) { stage = (int)c->max_win_full; lds += (size_t)stage * sizeof(double); }
     PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_em), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_CALLER_EM], c->stream));
     hipLaunchKernelGGL(pg::k_em, dim3(c->n_windows), dim3(64 * n_wav), lds, c->stream,
-                       c->d_wins.p, c->d_ioff.p, c->d_full.p, max_iters, n_max,
+                       c->d_wins.p, c->d_ioff.p, c->d_full.p, max_iters, n_max, stage,
                        c->d_freq.p, c->d_em_iters.p, c->d_em_change.p, c->d_best_gen.p, c->d_best_val.p);
     PG_HIP(c, hipGetLastError());
     PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_CALLER_EM + 1], c->stream));

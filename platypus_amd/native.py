@@ -36,6 +36,7 @@ SYMBOLS = {
     "pg_align_pairs": (C.c_int, [C.c_void_p, C.c_int64, _i32p, _i32p, _i32p, _i32p, _f64p]),
     "pg_kernel_time_ms": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
     "pg_genotype_loglik": (C.c_int, [C.c_void_p, C.c_int64, _i64p, _i64p, _i32p, _f64p]),
+    "pg_genotype_loglik_rows": (C.c_int, [C.c_void_p, C.c_int, _f64p, _f64p, C.POINTER(C.c_double)]),
     "pg_windows_upload": (C.c_int, [C.c_void_p, C.c_int, _i32p, _i32p, _i64p, _i32p]),
     "pg_caller_launch": (C.c_int, [C.c_void_p, C.c_int]),
     "pg_caller_fetch": (C.c_int, [C.c_void_p, _f64p, _i32p, _f64p, _i32p, _f64p, _f64p]),
@@ -167,6 +168,13 @@ class AlignContext(object):
         out = np.empty(len(b1), dtype=np.float64)
         self._check(LIB.pg_genotype_loglik(self._h, len(b1), _ptr(b1), _ptr(b2), _ptr(nr), _ptr(out)))
         return out
+
+    def genotype_loglik_rows(self, row1, row2):
+        r1 = _arr(row1, np.float64); r2 = _arr(row2, np.float64)
+        assert len(r1) == len(r2)
+        out = C.c_double(0)
+        self._check(LIB.pg_genotype_loglik_rows(self._h, len(r1), _ptr(r1), _ptr(r2), C.byref(out)))
+        return out.value
 
     # ---- genotype likelihoods, EM, variant posteriors over windows ----
 

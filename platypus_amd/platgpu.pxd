@@ -1,5 +1,5 @@
 # C ABI of libplatgpu.so (include/platgpu.h)
-from libc.stdint cimport int32_t, int64_t
+from libc.stdint cimport int32_t, int64_t, uint8_t
 
 cdef extern from "platgpu.h":
     ctypedef struct pg_ctx:
@@ -22,3 +22,11 @@ cdef extern from "platgpu.h":
     int pg_results_fetch(pg_ctx* ctx, int32_t* score, int32_t* anchor, double* likelihood)
     int pg_genotype_loglik(pg_ctx* ctx, int64_t n_gen, const int64_t* pair_base1, const int64_t* pair_base2,
                            const int32_t* n_reads, double* out)
+    int pg_windows_upload(pg_ctx* ctx, int n_windows, const int32_t* n_haps, const int32_t* n_inds,
+                          const int64_t* like_base, const int32_t* ind_read_off)
+    int pg_caller_launch(pg_ctx* ctx, int max_iters)
+    int pg_caller_fetch(pg_ctx* ctx, double* freq, int32_t* iters, double* max_change,
+                        int32_t* best_genotype, double* best_value, double* genotype_post)
+    int pg_variant_posteriors(pg_ctx* ctx, int n_vars, const int32_t* var_window,
+                              const uint8_t* hap_has_var, const double* prior, double* out)
+    int pg_genotype_loglik_rows(pg_ctx* ctx, int n_reads, const double* row1, const double* row2, double* out)

@@ -83,7 +83,9 @@ def test_haplotype_align_reads_prefetch_and_genotypes():
         g = 0
         for i in range(H):
             for j in range(i, H):
-                assert ll[0, g] == po.genotype_loglik(expected(w * H + i), expected(w * H + j))
+                want = po.genotype_loglik(expected(w * H + i), expected(w * H + j))
+                np.testing.assert_allclose(ll[0, g], want, rtol=1e-9)       # device log, fixed-tree sum
+                np.testing.assert_allclose(gts[g].calculateDataLikelihoodPy(buf, 0, 1), want, rtol=1e-9)
                 g += 1
     # single-pair entry point with the reference's signature
     h, r = 1, 3
@@ -93,4 +95,97 @@ def test_haplotype_align_reads_prefetch_and_genotypes():
                                     b["hap_seq"][b["hap_off"][h]:b["hap_off"][h + 1]].tobytes(),
                                     int(b["hap_start"][h]), int(b["hap_varlen"][h]), po.HOMOPOLQ)
     assert got == po.likelihood(exp_s[h * R + r], mq[r])
+    calign.closeDevice()
+
+
+class _Var(object):
+    """stand-in for platypus/variant.pyx Variant: hashable, comparable, with a prior"""
+    def __init__(self, name, prior):
+        self.name, self.prior = name, prior
+
+    def calculatePrior(self):
+        return self.prior
+
+    def __eq__(self, other):
+        return self.name == other.name
+
+    def __hash__(self):
+        return hash(self.name)
+
+
+def _buffer_of(b, ids):
+    from platypus_amd import cwindow
+    ids = np.asarray(ids, dtype=np.int64)
+    if len(ids) == 0:
+        z = np.zeros(0, np.int32)
+        return cwindow.bamReadBuffer(b"chr20", 0, 10, np.zeros(0, np.uint8), np.zeros(0, np.uint8),
+                                     np.zeros(1, np.int64), z, z, z)
+    ids = ids[np.argsort(b["read_pos"][ids], kind="stable")]
+    seq = np.concatenate([b["read_seq"][b["read_off"][r]:b["read_off"][r + 1]] for r in ids])
+    qual = np.concatenate([b["read_qual"][b["read_off"][r]:b["read_off"][r + 1]] for r in ids])
+    lens = b["read_off"][ids + 1] - b["read_off"][ids]
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    pos = b["read_pos"][ids]
+    buf = cwindow.bamReadBuffer(b"chr20", int(pos.min()), int(pos.max()) + 1000, seq, qual, off, pos,
+                                (pos + lens).astype(np.int32), b["read_mapq"][ids])
+    buf.setWindow(int(pos.min()), int(pos.max()) + 1)       # every read of the buffer is in the window
+    return ids, buf
+
+
+@pytest.mark.gpu
+def test_caller_setup_call_and_variant_posterior():
+    """Caller.setup / Caller.call / Population.calculatePosterior (cpopulation.pyx) against the CPU checker."""
+    from oracle import pyoracle as po
+    from platypus_amd import calign, cgenotype, chaplotype, cpopulation, synth
+    H, R = 5, 48
+    b = synth.make_batch(n_windows=4, haps_per_window=H, reads_per_window=R, read_len=80, hap_len=400,
+                         indel_hap_frac=0.4, seed=78)
+    exp_s, _ = po.run_pairs(synth.oracle_view(b), reuse_hash=True)
+    mq = b["read_mapq"]
+    for w in range(4):
+        variants = [_Var("v%d" % k, 10.0 ** -(1 + k % 3)) for k in range(H)]
+        haps = []
+        for k, h in enumerate(range(w * H, (w + 1) * H)):
+            seq = b["hap_seq"][b["hap_off"][h]:b["hap_off"][h + 1]].tobytes()
+            vs = () if k == 0 else ((variants[k],) if k != 2 else (variants[1], variants[2]))
+            haps.append(chaplotype.Haplotype(b"chr20", int(b["hap_start"][h]), int(b["hap_start"][h]) + len(seq),
+                                             seq, int(b["hap_varlen"][h]), vs))
+        reads = np.arange(w * R, (w + 1) * R)
+        groups = [reads[0::3], reads[:0], reads[1::3], reads[2::3]]      # the second individual has no reads
+        ids, bufs = [], []
+        for gsel in groups:
+            if len(gsel):
+                i, bf = _buffer_of(b, gsel)
+            else:
+                i, bf = np.zeros(0, np.int64), _buffer_of(b, gsel)
+            ids.append(i); bufs.append(bf)
+        assert [bf.readCount for bf in bufs] == [len(i) for i in ids]
+        order = np.concatenate(ids)
+        off = np.concatenate([[0], np.cumsum([len(i) for i in ids])]).astype(np.int32)
+        like = np.array([[po.likelihood(exp_s[h * R + (r - w * R)], mq[r]) for r in order]
+                         for h in range(w * H, (w + 1) * H)])
+        gts = cgenotype.allGenotypes(haps)
+        caller = cpopulation.Caller()
+        caller.setupPy(haps, gts, bufs)
+        pop = caller.callPy()
+        post = po.caller_setup(like, off)
+        ref = po.caller_call(post, off, H, want_cisr=True)
+        np.testing.assert_allclose(np.array(pop.genotypePosteriorsPy()), post, rtol=1e-9)
+        np.testing.assert_allclose(pop.frequenciesPy(), ref["freq"], rtol=1e-9, atol=1e-300)
+        assert pop.nIterations == ref["iters"]
+        assert pop.haplotypeIndexesPy() == [(a, c) for a in range(H) for c in range(a, H)]
+        for i in range(4):
+            if ref["best_gen"][i] < 0:
+                assert pop.genotypeCalls[i] is None and pop.genotypeLikelihoods[i] == 0.0
+            else:
+                assert pop.genotypeCalls[i] is gts[ref["best_gen"][i]]
+                np.testing.assert_allclose(pop.genotypeLikelihoods[i], ref["best_val"][i], rtol=1e-9)
+        for k in (1, 2, 4):
+            mask = [1 if variants[k] in hp.variantsPy() else 0 for hp in haps]
+            want = po.variant_posterior(post, off, ref["freq"], mask, variants[k].prior)
+            np.testing.assert_allclose(pop.calculatePosteriorPy(variants[k]), want, rtol=1e-8)
+        # the haplotypes' caches were filled by setup, as the reference's loop would have
+        assert all(hp.isCached(i) for hp in haps for i in range(4))
+    with pytest.raises(ValueError):
+        cpopulation.Caller().setupPy(haps, gts[::-1], bufs)
     calign.closeDevice()
