@@ -106,6 +106,16 @@ int pg_pairs_upload(pg_ctx *ctx, int64_t n_pairs, const int32_t *hap_idx, const 
 int pg_pairs_block(pg_ctx *ctx, int hap_lo, int hap_hi, int read_lo, int read_hi);
 
 /*
+ * Several dense blocks in one pair list, block after block, each haplotype-major
+ * like pg_pairs_block: the pairs of all windows collected for one launch (the
+ * double loop of platypus/cpopulation.pyx:698-725, window after window of
+ * platypus/variantcaller.pyx:116-187).  pair_base (may be NULL) receives the index of
+ * every block's first pair, which is the like_base pg_windows_upload takes.
+ */
+int pg_pairs_blocks(pg_ctx *ctx, int n_blocks, const int32_t *hap_lo, const int32_t *n_haps,
+                    const int32_t *read_lo, const int32_t *n_reads, int64_t *pair_base);
+
+/*
  * Enqueue the anchoring and alignment kernels for the uploaded pairs on the
  * context's stream (asynchronous).  Per pair this computes what
  * alignNoTraceback does (platypus/calign.pyx:36-78): anchor =

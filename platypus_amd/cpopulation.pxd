@@ -14,6 +14,8 @@ cdef class Population:
     cdef list readBuffers
     cdef public int nIterations
     cdef public double maxChange
+    cdef public int windowIndex
+    cdef long generation
     cdef double calculatePosterior(self, object var) except? -1.0
 
 
@@ -30,3 +32,11 @@ cdef class Caller:
     cdef object options
     cdef Population call(self, int maxIters=*)
     cdef setup(self, list haplotypes, list genotypes, int nInd, int ploidy, int verbosity, list readBuffers)
+
+
+# collect -> run -> consume over many windows (the rework of the window loop of
+# platypus/variantcaller.pyx:116-187 into device batches)
+cdef class WindowBatch:
+    cdef list windows
+    cdef public list populations
+    cdef public dict timings

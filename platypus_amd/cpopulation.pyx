@@ -15,11 +15,15 @@ path and are not mirrored.
 """
 from libc.stdint cimport int32_t, int64_t, uint8_t
 from libc.stdlib cimport malloc, calloc, free
+from libc.string cimport memcpy
+import time
 
 from platypus_amd.calign cimport deviceContext
 from platypus_amd.calign import PlatGpuError
 from platypus_amd.chaplotype cimport Haplotype, prefetchWindowC
-from platypus_amd.cgenotype cimport DiploidGenotype
+from platypus_amd.cgenotype cimport DiploidGenotype, generateAllGenotypesFromHaplotypeList
+from platypus_amd.calign cimport setParams
+from platypus_amd.samtoolsWrapper cimport cAlignedRead
 from platypus_amd.cwindow cimport bamReadBuffer
 from platypus_amd.platgpu cimport *
 
@@ -29,6 +33,11 @@ cdef int check(pg_ctx* ctx, int rc) except -1:
         msg = pg_last_error_string(ctx)
         raise PlatGpuError("libplatgpu error %d: %s" % (rc, msg.decode() if msg != NULL else ""))
     return 0
+
+
+# Results of the genotype / EM kernels stay on the device until the next windows are
+# uploaded; a Population remembers which upload it came from.
+cdef long g_generation = 0
 
 
 cdef class Population:
@@ -51,13 +60,16 @@ cdef class Population:
         """Posterior that `var` segregates (cpopulation.pyx:515-632).  `var` needs
         calculatePrior() and must be comparable with the entries of Haplotype.variants."""
         cdef pg_ctx* ctx = deviceContext()
-        cdef int32_t win = 0
+        cdef int32_t win = self.windowIndex
         cdef double prior = var.calculatePrior()
         cdef double out = 0.0
         cdef int i
         cdef Haplotype hap
         if self.nHaplotypes > 1000:
             raise ValueError("Too many haplotypes (%s). This should never happen" % self.nHaplotypes)
+        if self.generation != g_generation:
+            raise PlatGpuError("this Population's results have left the device (another window or batch was "
+                               "called since); evaluate variants before the next call")
         cdef uint8_t* mask = <uint8_t*>malloc(self.nHaplotypes)
         try:
             for i in range(self.nHaplotypes):
@@ -147,6 +159,10 @@ cdef class Caller:
             for i in range(nI):
                 off[i + 1] = off[i] + self.nReads[i]
                 pop.nReads[i] = self.nReads[i]
+            global g_generation
+            g_generation += 1
+            pop.generation = g_generation
+            pop.windowIndex = 0
             check(ctx, pg_windows_upload(ctx, 1, &n_haps, &n_inds, &like_base, off))
             check(ctx, pg_caller_launch(ctx, maxIters))
             check(ctx, pg_caller_fetch(ctx, pop.frequencies, &iters, &change, best, val, post))
@@ -180,3 +196,235 @@ cdef class Caller:
 
     def callPy(self, int maxIters=100):
         return self.call(maxIters)
+
+
+cdef Population makePopulation(list haplotypes, list genotypes, list readBuffers, int nI, const int32_t* nReads,
+                               const double* freq, const double* post, const int32_t* best, const double* val,
+                               int iters, double change, int windowIndex):
+    """A Population from the flat results of one window of a batch."""
+    cdef int nH = len(haplotypes), nG = nH * (nH + 1) // 2, i, g, a, b
+    cdef Population pop = Population.__new__(Population)
+    pop.nHaplotypes = nH; pop.nIndividuals = nI; pop.nGenotypes = nG
+    pop.haplotypes = haplotypes; pop.readBuffers = readBuffers; pop.verbosity = 0
+    pop.frequencies = <double*>malloc((nH if nH > 0 else 1) * sizeof(double))
+    memcpy(pop.frequencies, freq, nH * sizeof(double))
+    pop.nReads = <int*>malloc((nI if nI > 0 else 1) * sizeof(int))
+    pop.genotypePosteriors = <double**>calloc(nI, sizeof(double*))
+    pop.haplotypeIndexes = <int**>calloc(nG, sizeof(int*))
+    pop.nIterations = iters
+    pop.maxChange = change
+    pop.windowIndex = windowIndex
+    pop.generation = g_generation
+    pop.genotypeCalls = []
+    pop.genotypeLikelihoods = []
+    for i in range(nI):
+        pop.nReads[i] = nReads[i]
+        pop.genotypePosteriors[i] = <double*>malloc(nG * sizeof(double))
+        memcpy(pop.genotypePosteriors[i], post + <size_t>i * nG, nG * sizeof(double))
+        if best[i] < 0:                                   # cpopulation.pyx:777-780
+            pop.genotypeCalls.append(None)
+            pop.genotypeLikelihoods.append(0.0)
+        else:
+            pop.genotypeCalls.append(genotypes[best[i]])
+            pop.genotypeLikelihoods.append(val[i])
+    g = 0
+    for a in range(nH):
+        for b in range(a, nH):
+            pop.haplotypeIndexes[g] = <int*>malloc(2 * sizeof(int))
+            pop.haplotypeIndexes[g][0] = a
+            pop.haplotypeIndexes[g][1] = b
+            g += 1
+    return pop
+
+
+cdef class WindowBatch:
+    """Collects windows and calls them all in one device batch.
+
+    The reference handles one window at a time: set the window pointers, build the
+    haplotypes, Caller.setup, Caller.call, write the calls (variantcaller.pyx:116-187).
+    Here the loop is split: ``add`` takes a window's haplotypes and the individuals'
+    read buffers (whose window pointers are snapshotted, so the caller may move on to the
+    next window), ``run`` uploads everything collected, runs ONE alignment launch and ONE
+    genotype/EM launch for all windows, and returns a Population per window, in the order
+    of the ``add`` calls.  ``posteriors`` evaluates many (window, variant) pairs in one call.
+    """
+
+    def __init__(self):
+        self.windows = []
+        self.populations = []
+        self.timings = {}
+
+    def __len__(self):
+        return len(self.windows)
+
+    def add(self, list haplotypes, list readBuffers):
+        """Returns the window's index in this batch.  A window without any read is refused
+        (the reference divides by zero there, cpopulation.pyx:883)."""
+        cdef bamReadBuffer buf
+        cdef int i, n, tot = 0
+        cdef list counts = []
+        cdef list ptrs = []
+        cdef size_t p
+        cdef cAlignedRead** ws
+        if len(haplotypes) < 1 or len(haplotypes) > 1000:
+            raise ValueError("a window needs 1..1000 haplotypes (cpopulation.pyx:546)")
+        for i in range(len(readBuffers)):
+            buf = readBuffers[i]
+            n = <int>(buf.windowEnd - buf.windowStart)
+            ws = buf.windowStart
+            counts.append(n)
+            ptrs.append([<size_t>ws[r] for r in range(n)])
+            tot += n
+        if tot == 0:
+            raise ValueError("the window has no reads")
+        self.windows.append((haplotypes, readBuffers, counts, ptrs))
+        return len(self.windows) - 1
+
+    def run(self, int maxIters=100):
+        cdef pg_ctx* ctx = deviceContext()
+        cdef int nW = len(self.windows), w, h, i, r, n
+        cdef int64_t nHapTot = 0, nReadTot = 0, nIndTot = 0, hapBytes = 0, readBytes = 0, nCells = 0
+        cdef Haplotype hap
+        cdef cAlignedRead* rd
+        cdef size_t p
+        if nW == 0:
+            return []
+        t0 = time.perf_counter()
+        for w in range(nW):
+            haps, bufs, counts, ptrs = self.windows[w]
+            nHapTot += len(haps)
+            nIndTot += len(bufs)
+            nCells += <int64_t>len(bufs) * (len(haps) * (len(haps) + 1) // 2)
+            for hp in haps:
+                hap = hp
+                hapBytes += hap.hapLen
+            for lst in ptrs:
+                nReadTot += len(lst)
+                for q in lst:
+                    p = q
+                    readBytes += (<cAlignedRead*>p).rlen
+        cdef int64_t* hoff = <int64_t*>malloc((nHapTot + 1) * sizeof(int64_t))
+        cdef int32_t* hstart = <int32_t*>malloc((nHapTot + 1) * sizeof(int32_t))
+        cdef int32_t* hvl = <int32_t*>malloc((nHapTot + 1) * sizeof(int32_t))
+        cdef char* hbuf = <char*>malloc(hapBytes + 1)
+        cdef int64_t* roff = <int64_t*>malloc((nReadTot + 1) * sizeof(int64_t))
+        cdef int32_t* rpos = <int32_t*>malloc((nReadTot + 1) * sizeof(int32_t))
+        cdef int32_t* rmq = <int32_t*>malloc((nReadTot + 1) * sizeof(int32_t))
+        cdef char* sbuf = <char*>malloc(readBytes + 1)
+        cdef char* qbuf = <char*>malloc(readBytes + 1)
+        cdef int32_t* b_hlo = <int32_t*>malloc((nW + 1) * sizeof(int32_t))
+        cdef int32_t* b_nh = <int32_t*>malloc((nW + 1) * sizeof(int32_t))
+        cdef int32_t* b_rlo = <int32_t*>malloc((nW + 1) * sizeof(int32_t))
+        cdef int32_t* b_nr = <int32_t*>malloc((nW + 1) * sizeof(int32_t))
+        cdef int32_t* w_ni = <int32_t*>malloc((nW + 1) * sizeof(int32_t))
+        cdef int64_t* base = <int64_t*>malloc((nW + 1) * sizeof(int64_t))
+        cdef int32_t* ioff = <int32_t*>malloc((nIndTot + nW + 1) * sizeof(int32_t))
+        cdef int32_t* nreads = <int32_t*>malloc((nIndTot + 1) * sizeof(int32_t))
+        cdef double* freq = <double*>malloc((nHapTot + 1) * sizeof(double))
+        cdef int32_t* iters = <int32_t*>malloc((nW + 1) * sizeof(int32_t))
+        cdef double* change = <double*>malloc((nW + 1) * sizeof(double))
+        cdef int32_t* best = <int32_t*>malloc((nIndTot + 1) * sizeof(int32_t))
+        cdef double* val = <double*>malloc((nIndTot + 1) * sizeof(double))
+        cdef double* post = <double*>malloc((nCells + 1) * sizeof(double))
+        cdef int64_t hi = 0, ri = 0, ii = 0, oi = 0, ci = 0
+        cdef list out = []
+        global g_generation
+        try:
+            hoff[0] = 0
+            roff[0] = 0
+            for w in range(nW):
+                haps, bufs, counts, ptrs = self.windows[w]
+                b_hlo[w] = <int32_t>hi
+                b_nh[w] = len(haps)
+                b_rlo[w] = <int32_t>ri
+                w_ni[w] = len(bufs)
+                for hp in haps:
+                    hap = hp
+                    memcpy(hbuf + hoff[hi], hap.cHaplotypeSequence, hap.hapLen)
+                    hoff[hi + 1] = hoff[hi] + hap.hapLen
+                    hstart[hi] = hap.startPos
+                    hvl[hi] = hap.varSeqLen
+                    hi += 1
+                ioff[oi] = 0
+                n = 0
+                for i in range(len(bufs)):
+                    for q in ptrs[i]:
+                        p = q
+                        rd = <cAlignedRead*>p
+                        memcpy(sbuf + roff[ri], rd.seq, rd.rlen)
+                        memcpy(qbuf + roff[ri], rd.qual, rd.rlen)
+                        roff[ri + 1] = roff[ri] + rd.rlen
+                        rpos[ri] = rd.pos
+                        rmq[ri] = rd.mapq
+                        ri += 1
+                    n += <int>counts[i]
+                    ioff[oi + i + 1] = n
+                    nreads[ii + i] = <int>counts[i]
+                oi += len(bufs) + 1
+                ii += len(bufs)
+                b_nr[w] = n
+            hap = self.windows[0][0][0]
+            setParams(hap.cHomopolQ, 3, 2)                       # chaplotype.pyx:264
+            t1 = time.perf_counter()
+            check(ctx, pg_haps_upload(ctx, <int>nHapTot, hbuf, hoff, hstart, hvl))
+            check(ctx, pg_reads_upload(ctx, <int>nReadTot, sbuf, qbuf, roff, rpos, rmq))
+            check(ctx, pg_pairs_blocks(ctx, nW, b_hlo, b_nh, b_rlo, b_nr, base))
+            t2 = time.perf_counter()
+            check(ctx, pg_align_launch(ctx))
+            g_generation += 1
+            check(ctx, pg_windows_upload(ctx, nW, b_nh, w_ni, base, ioff))
+            check(ctx, pg_caller_launch(ctx, maxIters))
+            check(ctx, pg_caller_fetch(ctx, freq, iters, change, best, val, post))
+            t3 = time.perf_counter()
+            hi = 0; ii = 0; ci = 0
+            for w in range(nW):
+                haps, bufs, counts, ptrs = self.windows[w]
+                gts = generateAllGenotypesFromHaplotypeList(2, haps)
+                out.append(makePopulation(haps, gts, bufs, len(bufs), nreads + ii, freq + hi, post + ci,
+                                          best + ii, val + ii, iters[w], change[w], w))
+                hi += len(haps)
+                ii += len(bufs)
+                ci += <int64_t>len(bufs) * (len(haps) * (len(haps) + 1) // 2)
+            t4 = time.perf_counter()
+            self.timings = dict(pack=t1 - t0, upload=t2 - t1, device=t3 - t2, unpack=t4 - t3,
+                                windows=nW, haplotypes=int(nHapTot), reads=int(nReadTot))
+        finally:
+            free(hoff); free(hstart); free(hvl); free(hbuf); free(roff); free(rpos); free(rmq); free(sbuf); free(qbuf)
+            free(b_hlo); free(b_nh); free(b_rlo); free(b_nr); free(w_ni); free(base); free(ioff); free(nreads)
+            free(freq); free(iters); free(change); free(best); free(val); free(post)
+        self.populations = out
+        return out
+
+    def posteriors(self, list items):
+        """[(window index, variant), ...] -> posteriors (cpopulation.pyx:515-632), one device call."""
+        cdef pg_ctx* ctx = deviceContext()
+        cdef int nV = len(items), v, k, nH
+        cdef int64_t tot = 0
+        cdef Population pop
+        cdef Haplotype hap
+        if nV == 0:
+            return []
+        for w, var in items:
+            pop = self.populations[w]
+            if pop.generation != g_generation:
+                raise PlatGpuError("the batch's results have left the device")
+            tot += pop.nHaplotypes
+        cdef int32_t* win = <int32_t*>malloc(nV * sizeof(int32_t))
+        cdef double* prior = <double*>malloc(nV * sizeof(double))
+        cdef double* res = <double*>malloc(nV * sizeof(double))
+        cdef uint8_t* mask = <uint8_t*>malloc(tot + 1)
+        tot = 0
+        try:
+            for v in range(nV):
+                w, var = items[v]
+                pop = self.populations[w]
+                win[v] = w
+                prior[v] = var.calculatePrior()
+                for k in range(pop.nHaplotypes):
+                    hap = pop.haplotypes[k]
+                    mask[tot + k] = 1 if var in hap.variants else 0
+                tot += pop.nHaplotypes
+            check(ctx, pg_variant_posteriors(ctx, nV, win, mask, prior, res))
+            return [res[v] for v in range(nV)]
+        finally:
+            free(win); free(prior); free(res); free(mask)

@@ -12,6 +12,7 @@
 //   k_norm        exp(ll - maximum of the window); also written as full symmetric
 //                 n x n matrices, the layout the EM streams
 //   k_em          EM iterations and genotype calls, one workgroup per window
+//   k_em_small    the same for windows of at most 8 haplotypes, one wavefront per window
 //   k_var_post    posterior of a variant given the haplotypes that carry it
 //
 // Sums over reads run in read order like the reference's; sums over genotypes
@@ -45,15 +46,34 @@ __device__ __forceinline__ int tri_row_of(int g, int n) {
     return a;
 }
 
-__device__ __forceinline__ double wave_sum(double v) {       // fixed butterfly: same result in every lane
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
+// Cross-lane reductions over a wavefront, result in every lane.  The partner of a lane is
+// fetched with DPP inside its row of 16 (quad swaps, then mirrors: once the lanes of a group
+// agree, any lane of the partner group will do) and the four row results are combined
+// through lane reads -- a fixed balanced tree, an order of magnitude less latency than
+// six LDS-crossbar shuffles.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_f64(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
+                            __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ __forceinline__ double wave_sum(double v) {
+    v += dpp_f64<0xB1>(v);        // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);        // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141>(v);       // row_half_mirror
+    v += dpp_f64<0x140>(v);       // row_mirror
+    return (lane_f64(v, 0) + lane_f64(v, 16)) + (lane_f64(v, 32) + lane_f64(v, 48));
 }
 __device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
-    return v;
+    v = fmax(v, dpp_f64<0xB1>(v));
+    v = fmax(v, dpp_f64<0x4E>(v));
+    v = fmax(v, dpp_f64<0x141>(v));
+    v = fmax(v, dpp_f64<0x140>(v));
+    return fmax(fmax(lane_f64(v, 0), lane_f64(v, 16)), fmax(lane_f64(v, 32), lane_f64(v, 48)));
 }
 
 // Order-preserving map of a double onto an unsigned 64-bit integer, so that the
@@ -348,6 +368,100 @@ __global__ __launch_bounds__(1024) void k_em(const WinDesc* __restrict__ wins,
     else
         em_window<false>(em_lds, s_red, &s_with_data, wins, ioff, full, max_iters, n_max,
                          freq_out, iters_out, change_out, best_gen, best_val);
+}
+
+// ---------------------------------------------------------------------------
+// k_em_small: the same computation for windows of at most 8 haplotypes (the
+// usual single-sample window has 2-4), one wavefront per window, everything in
+// registers.  Lane l < n^2 owns the matrix element (r, k) = (l / n, l % n); the
+// product sums its rows in row order through lane reads, the frequencies live
+// replicated in the lanes.  Every sum has the shape it has in k_em, so the two
+// kernels return the same doubles.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_em_small(const WinDesc* __restrict__ wins, int n_win,
+                                                  const int32_t* __restrict__ ioff,
+                                                  const double* __restrict__ full,
+                                                  int max_iters,
+                                                  double* __restrict__ freq_out, int32_t* __restrict__ iters_out,
+                                                  double* __restrict__ change_out, int32_t* __restrict__ best_gen,
+                                                  double* __restrict__ best_val)
+{
+    const int w = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256u + threadIdx.x) >> 6));
+    if (w >= n_win) return;
+    const int lane = threadIdx.x & 63;
+    const WinDesc W = wins[w];
+    const int n = W.n_hap, nn = n * n;
+    const int32_t* io = ioff + W.ioff_base;
+    const bool live = lane < nn;
+    const int r = live ? lane / n : 0, k = live ? lane % n : 0;
+    const double* Pw = full + W.full_base;
+    int n_with_data = 0;
+    for (int i = 0; i < W.n_ind; ++i) n_with_data += io[i + 1] != io[i];
+    double eps = 1.0 / (W.n_ind * 2 * 2);                                    // cpopulation.pyx:751
+    eps = eps < 1e-3 ? eps : 1e-3;
+    double max_change = eps + 1;
+    int iters = 0;
+    double fk = 1.0 / n, fr = 1.0 / n, fk_prev = fk, fr_prev = fr;           // f[k], f[r] of this lane
+    const double P0 = live ? Pw[lane] : 0.0;                                  // individual 0 stays in a register
+
+    // y_k (valid in lanes with r == 0, i.e. lanes 0..n-1) and csrSum for individual i
+    auto matvec = [&](int i, double f_r, double f_k, double& y) -> double {
+        const double p = i == 0 ? P0 : (live ? Pw[(int64_t)i * nn + lane] : 0.0);
+        const double t = p * f_r;
+        y = 0.0;
+        for (int rr = 0; rr < n; ++rr) y += __shfl(t, rr * n + k);          // rows in row order
+        return wave_sum((live && r == 0) ? f_k * y : 0.0);
+    };
+
+    while (max_change > eps && iters < max_iters) {                          // :766-768
+        double acc = 0.0;
+        for (int i = 0; i < W.n_ind; ++i) {
+            if (io[i + 1] == io[i]) continue;                                // :834-835
+            double y;
+            const double s = matvec(i, fr, fk, y);
+            const double t = 2.0 * fk * y;
+            acc += s > 0.0 ? t / s : t;                                      // :852-854
+        }
+        const double nf = (0.0 + acc) / (2 * n_with_data);                   // :883
+        const double ch = wave_max((live && r == 0) ? fabs(fk - nf) : 0.0);  // :885-888
+        max_change = ch;
+        fk_prev = fk; fr_prev = fr;
+        // lanes 0..n-1 hold the new f_k for k = lane; every lane picks up its own k and r
+        fk = __shfl(nf, k);
+        fr = __shfl(nf, r);
+        ++iters;
+    }
+    if (lane < n) freq_out[W.hap_base + lane] = fk;
+    if (lane == 0) { iters_out[w] = iters; change_out[w] = max_change; }
+
+    for (int i = 0; i < W.n_ind; ++i) {                                      // :773-797
+        if (io[i + 1] == io[i]) {
+            if (lane == 0) { best_gen[W.ind_base + i] = -1; best_val[W.ind_base + i] = 0.0; }
+            continue;
+        }
+        if (iters == 0) {
+            if (lane == 0) { best_gen[W.ind_base + i] = 0; best_val[W.ind_base + i] = 0.0; }
+            continue;
+        }
+        double y;
+        const double s = matvec(i, fr_prev, fk_prev, y);
+        const double p = i == 0 ? P0 : (live ? Pw[(int64_t)i * nn + lane] : 0.0);
+        double bv = 0.0;
+        int bj = 0x7fffffff;
+        if (live && r <= k) {                                                // genotype (a, b) = (r, k)
+            double v = p * fr_prev * fk_prev * (1 + (r != k));               // :847
+            if (s > 0.0) v /= s;
+            bv = v;
+            bj = (int)(tri_row_start(r, n) + k - r);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ov = __shfl_xor(bv, off);
+            const int oj = __shfl_xor(bj, off);
+            if (oj != 0x7fffffff && (bj == 0x7fffffff || ov > bv || (ov == bv && oj < bj))) { bv = ov; bj = oj; }
+        }
+        if (lane == 0) { best_gen[W.ind_base + i] = bj; best_val[W.ind_base + i] = bv; }
+    }
 }
 
 // ---------------------------------------------------------------------------

@@ -475,6 +475,28 @@ int pg_pairs_block(pg_ctx* c, int hap_lo, int hap_hi, int read_lo, int read_hi) 
     return pg_pairs_upload(c, nh * nr, hi.data(), ri.data());
 }
 
+int pg_pairs_blocks(pg_ctx* c, int nb, const int32_t* hap_lo, const int32_t* n_haps,
+                    const int32_t* read_lo, const int32_t* n_reads, int64_t* pair_base) {
+    if (!c) return PG_ERR_INVALID;
+    if (nb < 0 || (nb > 0 && (!hap_lo || !n_haps || !read_lo || !n_reads)))
+        return fail(c, PG_ERR_INVALID, "pg_pairs_blocks: bad arguments");
+    int64_t total = 0;
+    for (int b = 0; b < nb; ++b) {
+        if (hap_lo[b] < 0 || n_haps[b] < 0 || (int64_t)hap_lo[b] + n_haps[b] > c->n_haps || read_lo[b] < 0 ||
+            n_reads[b] < 0 || (int64_t)read_lo[b] + n_reads[b] > c->n_reads)
+            return fail(c, PG_ERR_INVALID, "pg_pairs_blocks: block %d reaches outside the uploaded batches", b);
+        if (pair_base) pair_base[b] = total;
+        total += (int64_t)n_haps[b] * n_reads[b];
+    }
+    if (total > 0x7fffffffLL) return fail(c, PG_ERR_INVALID, "pg_pairs_blocks: %lld pairs", (long long)total);
+    std::vector<int32_t> hi((size_t)total), ri((size_t)total);
+    int64_t p = 0;
+    for (int b = 0; b < nb; ++b)
+        for (int32_t h = 0; h < n_haps[b]; ++h)
+            for (int32_t r = 0; r < n_reads[b]; ++r, ++p) { hi[p] = hap_lo[b] + h; ri[p] = read_lo[b] + r; }
+    return pg_pairs_upload(c, total, hi.data(), ri.data());
+}
+
 int pg_align_launch(pg_ctx* c) {
     if (!c) return PG_ERR_INVALID;
     if (c->n_pairs == 0) return fail(c, PG_ERR_STATE, "no pairs uploaded");
@@ -697,9 +719,16 @@ int pg_caller_launch(pg_ctx* c, int max_iters) {
     if (c->max_win_full <= 4096) { stage = (int)c->max_win_full; lds += (size_t)stage * sizeof(double); }
     PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_em), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_CALLER_EM], c->stream));
-    hipLaunchKernelGGL(pg::k_em, dim3(c->n_windows), dim3(64 * n_wav), lds, c->stream,
-                       c->d_wins.p, c->d_ioff.p, c->d_full.p, max_iters, n_max, stage,
-                       c->d_freq.p, c->d_em_iters.p, c->d_em_change.p, c->d_best_gen.p, c->d_best_val.p);
+    const char* force = std::getenv("PG_EM_KERNEL");        // experiments: "big" forces the general kernel
+    if (n_max <= 8 && !(force && force[0] == 'b')) {
+        hipLaunchKernelGGL(pg::k_em_small, dim3((c->n_windows + 3) / 4), dim3(256), 0, c->stream,
+                           c->d_wins.p, c->n_windows, c->d_ioff.p, c->d_full.p, max_iters,
+                           c->d_freq.p, c->d_em_iters.p, c->d_em_change.p, c->d_best_gen.p, c->d_best_val.p);
+    } else {
+        hipLaunchKernelGGL(pg::k_em, dim3(c->n_windows), dim3(64 * n_wav), lds, c->stream,
+                           c->d_wins.p, c->d_ioff.p, c->d_full.p, max_iters, n_max, stage,
+                           c->d_freq.p, c->d_em_iters.p, c->d_em_change.p, c->d_best_gen.p, c->d_best_val.p);
+    }
     PG_HIP(c, hipGetLastError());
     PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_CALLER_EM + 1], c->stream));
     c->ev_valid[PG_K_CALLER_EM] = true;

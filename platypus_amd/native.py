@@ -30,6 +30,7 @@ SYMBOLS = {
     "pg_reads_upload": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _i64p, _i32p, _i32p]),
     "pg_pairs_upload": (C.c_int, [C.c_void_p, C.c_int64, _i32p, _i32p]),
     "pg_pairs_block": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "pg_pairs_blocks": (C.c_int, [C.c_void_p, C.c_int, _i32p, _i32p, _i32p, _i32p, _i64p]),
     "pg_align_launch": (C.c_int, [C.c_void_p]),
     "pg_sync": (C.c_int, [C.c_void_p]),
     "pg_results_fetch": (C.c_int, [C.c_void_p, _i32p, _i32p, _f64p]),
@@ -131,6 +132,15 @@ class AlignContext(object):
     def pairs_block(self, hap_lo, hap_hi, read_lo, read_hi):
         self._check(LIB.pg_pairs_block(self._h, hap_lo, hap_hi, read_lo, read_hi))
         self.n_pairs = (hap_hi - hap_lo) * (read_hi - read_lo)
+
+    def pairs_blocks(self, hap_lo, n_haps, read_lo, n_reads):
+        """dense blocks back to back; returns the index of each block's first pair"""
+        hl = _arr(hap_lo, np.int32); nh = _arr(n_haps, np.int32)
+        rl = _arr(read_lo, np.int32); nr = _arr(n_reads, np.int32)
+        base = np.zeros(len(hl), dtype=np.int64)
+        self._check(LIB.pg_pairs_blocks(self._h, len(hl), _ptr(hl), _ptr(nh), _ptr(rl), _ptr(nr), _ptr(base)))
+        self.n_pairs = int((nh.astype(np.int64) * nr).sum())
+        return base
 
     def launch(self):
         self._check(LIB.pg_align_launch(self._h))

@@ -30,3 +30,5 @@ cdef extern from "platgpu.h":
     int pg_variant_posteriors(pg_ctx* ctx, int n_vars, const int32_t* var_window,
                               const uint8_t* hap_has_var, const double* prior, double* out)
     int pg_genotype_loglik_rows(pg_ctx* ctx, int n_reads, const double* row1, const double* row2, double* out)
+    int pg_pairs_blocks(pg_ctx* ctx, int n_blocks, const int32_t* hap_lo, const int32_t* n_haps,
+                        const int32_t* read_lo, const int32_t* n_reads, int64_t* pair_base)

@@ -189,3 +189,62 @@ def test_caller_setup_call_and_variant_posterior():
     with pytest.raises(ValueError):
         cpopulation.Caller().setupPy(haps, gts[::-1], bufs)
     calign.closeDevice()
+
+
+@pytest.mark.gpu
+def test_window_batch_equals_window_by_window():
+    """WindowBatch (collect -> one alignment launch + one genotype/EM launch -> consume) returns, window for
+    window, what Caller.setup / Caller.call return one window at a time."""
+    from platypus_amd import calign, cgenotype, chaplotype, cpopulation, synth
+    H, R, W = 4, 36, 12
+    b = synth.make_batch(n_windows=W, haps_per_window=H, reads_per_window=R, read_len=70, hap_len=360,
+                         indel_hap_frac=0.4, seed=79)
+    wins = []
+    for w in range(W):
+        variants = [_Var("w%dv%d" % (w, k), 1e-3) for k in range(H)]
+        haps = []
+        for k, h in enumerate(range(w * H, (w + 1) * H)):
+            seq = b["hap_seq"][b["hap_off"][h]:b["hap_off"][h + 1]].tobytes()
+            haps.append(chaplotype.Haplotype(b"chr20", int(b["hap_start"][h]), int(b["hap_start"][h]) + len(seq),
+                                             seq, int(b["hap_varlen"][h]), () if k == 0 else (variants[k],)))
+        reads = np.arange(w * R, (w + 1) * R)
+        bufs = [_buffer_of(b, reads[0::2])[1], _buffer_of(b, reads[1::2])[1]]
+        wins.append((haps, bufs, variants))
+    # one window at a time
+    single = []
+    for haps, bufs, variants in wins:
+        caller = cpopulation.Caller()
+        caller.setupPy(haps, cgenotype.allGenotypes(haps), bufs)
+        pop = caller.callPy()
+        single.append((pop.frequenciesPy(), pop.genotypePosteriorsPy(), pop.nIterations, list(pop.genotypeLikelihoods),
+                       [None if g is None else (g.haplotypes[0], g.haplotypes[1]) for g in pop.genotypeCalls],
+                       [pop.calculatePosteriorPy(v) for v in variants[1:]]))
+    # all windows in one batch; the buffers' window pointers may move on after add()
+    batch = cpopulation.WindowBatch()
+    for haps, bufs, _ in wins:
+        assert batch.add(haps, bufs) == len(batch) - 1
+        for bf in bufs:
+            bf.setWindow(0, 1)
+    pops = batch.run()
+    assert len(pops) == W and batch.timings["windows"] == W
+    post = batch.posteriors([(w, v) for w in range(W) for v in wins[w][2][1:]])
+    k = 0
+    for w, pop in enumerate(pops):
+        f, gp, it, gl, calls, vp = single[w]
+        assert pop.frequenciesPy() == f and pop.genotypePosteriorsPy() == gp and pop.nIterations == it
+        assert list(pop.genotypeLikelihoods) == gl
+        assert [None if g is None else (g.haplotypes[0], g.haplotypes[1]) for g in pop.genotypeCalls] == calls
+        assert post[k:k + len(vp)] == vp
+        k += len(vp)
+    # a Population of an earlier call can no longer reach its results on the device
+    caller = cpopulation.Caller()
+    caller.setupPy(wins[0][0], cgenotype.allGenotypes(wins[0][0]), wins[0][1])
+    with pytest.raises(ValueError):
+        cpopulation.WindowBatch().add(wins[0][0], wins[0][1])      # window pointers were moved: no reads
+    for bf in wins[0][1]:
+        bf.setWindow(0, 2 ** 30)
+    caller.setupPy(wins[0][0], cgenotype.allGenotypes(wins[0][0]), wins[0][1])
+    caller.callPy()
+    with pytest.raises(calign.PlatGpuError):
+        pops[0].calculatePosteriorPy(wins[0][2][1])
+    calign.closeDevice()

@@ -111,3 +111,28 @@ def test_window_errors():
             ctx.upload_windows([3], [2], [0], [0, 9, 8])
     finally:
         ctx.close()
+
+
+def test_small_window_kernel_equals_general_kernel(monkeypatch):
+    """Windows of at most 8 haplotypes take a one-wavefront-per-window kernel; its sums have the
+    shape of the general kernel's, so both return the same doubles."""
+    from platypus_amd import native
+    H, R, n_ind, nw = 7, 40, 3, 50
+    b = synth.make_batch(n_windows=nw, haps_per_window=H, reads_per_window=R, read_len=50, hap_len=260,
+                         indel_hap_frac=0.3, seed=21)
+    rng = np.random.default_rng(3)
+    offs = np.concatenate([split_reads(rng, R, n_ind, 1 if w % 4 == 0 else None) for w in range(nw)])
+    out = {}
+    for which in ("small", "big"):
+        monkeypatch.setenv("PG_EM_KERNEL", which)
+        ctx = native.AlignContext(0)
+        try:
+            ctx.upload_batch(b)
+            ctx.launch()
+            ctx.upload_windows([H] * nw, [n_ind] * nw, np.arange(nw, dtype=np.int64) * H * R, offs)
+            ctx.caller_launch(100)
+            out[which] = ctx.caller_fetch()
+        finally:
+            ctx.close()
+    for k in ("freq", "iters", "max_change", "best_gen", "best_val", "post"):
+        assert np.array_equal(out["small"][k], out["big"][k]), k

@@ -19,6 +19,7 @@ from platypus_amd import native, synth  # noqa: E402
 def main():
     wl = sys.argv[1] if len(sys.argv) > 1 else "wgs"
     windows = int(sys.argv[2]) if len(sys.argv) > 2 else 32768
+    max_iters = int(sys.argv[3]) if len(sys.argv) > 3 else 100
     H, R, extra, _ = bench.WORKLOADS[wl]
     n_ind = 50 if wl == "joint" else 1
     nw = max(1, windows * 128 // (H * R))
@@ -31,7 +32,7 @@ def main():
     for rep in range(3):
         ctx.launch()
         t0 = time.perf_counter()
-        ctx.caller_launch(100)
+        ctx.caller_launch(max_iters)
         ctx.sync()
         dt = time.perf_counter() - t0
         print("rep %d: align %.3f ms  anchor %.3f ms | setup %.3f ms  em %.3f ms  (host wall of the caller stage %.3f ms)" % (
@@ -40,6 +41,9 @@ def main():
     res = ctx.caller_fetch(genotype_post=False)
     print("windows %d  haplotypes %d  individuals %d  genotypes %d  iterations: mean %.1f max %d" % (
         nw, H, n_ind, H * (H + 1) // 2, res["iters"].mean(), res["iters"].max()))
+    print("iteration histogram (<=5, <=10, <=20, <=50, <100, 100):",
+          [int(((res["iters"] > lo) & (res["iters"] <= hi)).sum()) for lo, hi in
+           ((0, 5), (5, 10), (10, 20), (20, 50), (50, 99), (99, 100))])
     # CPU restatement on a sample of windows (single thread)
     from oracle import pyoracle as po
     _, _, like = ctx.fetch()
@@ -48,7 +52,7 @@ def main():
     for w in range(ns):
         L = like[w * H * R:(w + 1) * H * R].reshape(H, R)
         post = po.caller_setup(L, off)
-        po.caller_call(post, off, H)
+        po.caller_call(post, off, H, max_iters=max_iters)
     dt = time.perf_counter() - t0
     print("CPU restatement (1 thread, one-pass EM form): %.3f ms per window on %d windows -> %.1f ms for all" % (
         dt / ns * 1e3, ns, dt / ns * nw * 1e3))
