@@ -152,7 +152,8 @@ int pg_kernel_time_ms(pg_ctx *ctx, int which, float *ms);
 /*
  * Genotype log-likelihoods from the likelihoods of the last launch, which
  * stay on the device: out[g] = sum over r in [0,n_reads) of
- * log(0.5*(L[pair_base1[g]+r] + L[pair_base2[g]+r])), summed in read order.
+ * log(0.5*(L[pair_base1[g]+r] + L[pair_base2[g]+r])) (64 partial sums over reads r, r+64, ...
+ * combined in a fixed tree: reproducible, equal to the read-order sum to rounding).
  * Replaces DiploidGenotype.calculateDataLikelihood (platypus/cgenotype.pyx:48-63)
  * for n_gen (genotype, individual) combinations; pair_base* are pair indices of
  * the first read of the two haplotypes' likelihood rows.  Relative error vs the

@@ -11,8 +11,8 @@ import sysconfig
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-MODULES = ["calign", "cwindow", "chaplotype", "cgenotype", "cpopulation"]
-PXD = ["samtoolsWrapper.pxd", "platgpu.pxd", "calign.pxd", "cwindow.pxd", "chaplotype.pxd", "cgenotype.pxd", "cpopulation.pxd"]
+MODULES = ["variant", "calign", "cwindow", "chaplotype", "cgenotype", "cpopulation"]
+PXD = ["samtoolsWrapper.pxd", "platgpu.pxd", "calign.pxd", "cwindow.pxd", "chaplotype.pxd", "cgenotype.pxd", "cpopulation.pxd", "variant.pxd"]
 
 
 def _ext_path(mod):

@@ -49,6 +49,47 @@ cdef class Haplotype:
         self.likesByIndCache = NULL
         self.lenCache = 0
 
+    @staticmethod
+    def fromVariants(bytes refName, int startPos, int endPos, tuple variants, refFile, int maxReadLength):
+        """The reference's constructor (chaplotype.pyx:50-86): pad the window by twice the read
+        length, clamp to the sequence, and apply the (sorted) variants to the reference
+        (getMutatedSequence, chaplotype.pyx:283-353).  `refFile` offers getSequence,
+        getCharacter and refs[name].SeqLength (platypus_amd.fastafile.FastaFile)."""
+        cdef int varSeqLen = 0, currentPos
+        for v in variants:
+            varSeqLen += abs(v.nAdded - v.nRemoved)                              # chaplotype.pyx:66-67
+        startPos = max(0, startPos - 2 * maxReadLength)                          # chaplotype.pyx:70-71
+        endPos = min(endPos + 2 * maxReadLength, refFile.refs[refName].SeqLength)
+        if len(variants) == 0:
+            seq = refFile.getSequence(refName, startPos, endPos)
+        else:
+            currentPos = startPos
+            bits = [refFile.getSequence(refName, currentPos, variants[0].refPos)]
+            currentPos = variants[0].refPos
+            for v in variants:
+                if v.refPos > currentPos:                      # up to the next variant
+                    bits.append(refFile.getSequence(refName, currentPos, v.refPos))
+                    currentPos = v.refPos
+                if v.nAdded == v.nRemoved:                     # SNP / multi-nucleotide substitution
+                    bits.append(v.added)
+                    currentPos += v.nAdded
+                elif v.nAdded == 0 and v.nRemoved > 0:         # deletion: position = base before it
+                    if v.refPos == currentPos:
+                        bits.append(refFile.getCharacter(refName, v.refPos))
+                        currentPos += 1
+                    currentPos += v.nRemoved
+                elif v.nAdded > 0 and v.nRemoved == 0:         # insertion after the base at refPos
+                    if v.refPos == currentPos:
+                        bits.append(refFile.getCharacter(refName, v.refPos))
+                        currentPos += 1
+                    bits.append(v.added)
+                else:
+                    raise ValueError("Variant type %s not yet supported in getMutatedSequence()" % (v,))
+            if currentPos < endPos:
+                bits.append(refFile.getSequence(refName, currentPos, endPos))
+            seq = b"".join(bits)
+        return Haplotype(refName, startPos, endPos, seq, varSeqLen, variants)
+
     def __dealloc__(self):
         cdef int index
         if self.lenCache > 0:
@@ -106,6 +147,18 @@ cdef class Haplotype:
 
     def variantsPy(self):
         return self.variants
+
+    @property
+    def startPosPy(self):
+        return self.startPos
+
+    @property
+    def endPosPy(self):
+        return self.endPos
+
+    @property
+    def varSeqLenPy(self):
+        return self.varSeqLen
 
     property sequence:
         def __get__(self):

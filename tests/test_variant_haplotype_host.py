@@ -1,0 +1,94 @@
+"""Host-side pieces around the path: the Variant record (platypus/variant.pyx:19-250), the FASTA access
+rules (platypus/fastafile.pyx:91-174) and Haplotype construction from variants
+(platypus/chaplotype.pyx:50-86,283-353).  Expectations are worked out by hand from the reference's rules."""
+import os
+
+import numpy as np
+import pytest
+
+from platypus_amd.fastafile import FastaFile
+from platypus_amd.variant import Variant
+
+REF = b"ACGTACGTACGTACGTACGTAAAAACCCCCGGGGGTTTTTACGTACGTAC"      # 50 bases
+
+
+def test_variant_fields_and_prior():
+    snp = Variant(b"20", 100, b"A", b"C", 1, 1, 60, 30, 7)
+    assert (snp.minPos, snp.maxPos, snp.nAdded, snp.nRemoved, snp.nRevReads) == (100, 100, 1, 1, 0)
+    assert snp.calculatePrior() == 1e-3
+    assert snp.rmsReadPos == 7.0 and abs(snp.nFwdReadsWeighted - (1 - 10 ** -3)) < 1e-15 and snp.nRevReadsWeighted == 0.0
+    mnp = Variant(b"20", 100, b"AC", b"GT")
+    assert mnp.maxPos == 101 and mnp.calculatePrior() == 5e-5 * 0.1 ** 2
+    ins = Variant(b"20", 100, b"", b"GGG", 1, 0, 60, 20, 3)
+    assert ins.maxPos == 103 and ins.calculatePrior() == 1e-4 * 0.33 ** 3
+    assert ins.nFwdReadsWeighted == 0.0 and abs(ins.nRevReadsWeighted - 0.99) < 1e-15
+    dele = Variant(b"20", 100, b"TT", b"")
+    assert dele.maxPos == 102 and dele.calculatePrior() == 1e-4 * 0.8 ** 2
+    with pytest.raises(ValueError):
+        Variant(b"20", 100, b"TT", b"A").calculatePrior()
+    dele.freqPrior = 0.25
+    assert dele.calculatePrior() == 0.25
+    assert Variant(b"20", -5, b"A", b"C").refPos == 0                  # variant.pyx:38
+
+
+def test_variant_identity_order_and_merge():
+    a = Variant(b"20", 100, b"A", b"C", 1, 1, 60, 30, 3)
+    b = Variant(b"20", 100, b"A", b"C", 1, 0, 60, 30, 4)
+    c = Variant(b"20", 100, b"A", b"G")
+    assert a == b and hash(a) == hash(b) and a != c and len({a, b, c}) == 2
+    a.addVariant(b)
+    assert (a.nSupportingReads, a.nFwdReads, a.nRevReads) == (2, 1, 1)
+    assert abs(a.rmsReadPos - np.sqrt((9 + 16) / 2.0)) < 1e-15
+    # order: name, position, |length change| -- SNPs before indels at one position (variant.pyx:133-141)
+    ins = Variant(b"20", 100, b"", b"GG")
+    dele = Variant(b"20", 100, b"T", b"")
+    early = Variant(b"20", 99, b"", b"GGGG")
+    other = Variant(b"3", 5, b"A", b"C")
+    assert sorted([ins, dele, c, early, other]) == [early, c, dele, ins, other]
+    assert not (c < a) and c <= a and c >= a                            # same key, different alleles
+
+
+def test_fasta_access_rules(tmp_path):
+    mem = FastaFile(sequences={b"c": REF.lower()})
+    fa = tmp_path / "r.fa"
+    fa.write_bytes(b">c desc\n" + b"\n".join(REF[i:i + 12].lower() for i in range(0, 50, 12)) + b"\n>d\nACGT\n")
+    (tmp_path / "r.fa.fai").write_bytes(b"c\t50\t8\t12\t13\nd\t4\t66\t4\t5\n")
+    disk = FastaFile(str(fa), str(fa) + ".fai")
+    for f in (mem, disk):
+        assert f.refs[b"c"].SeqLength == 50
+        assert f.getSequence(b"c", 0, 10) == REF[:10]
+        assert f.getSequence(b"c", 10, 30) == REF[10:30]
+        assert f.getSequence(b"c", -5, 4) == REF[:4]
+        assert f.getSequence(b"c", 40, 60) == REF[40:49]               # the end is clamped to length - 1
+        assert f.getCharacter(b"c", 0) == b"A" and f.getCharacter(b"c", 49) == b"C"
+        assert f.getCharacter(b"c", 50) == b"-" and f.getCharacter(b"c", -1) == b"-"
+        with pytest.raises(IndexError):
+            f.getSequence(b"c", 30, 20)
+    assert disk.getSequence(b"d", 0, 3) == b"ACG" and disk.getTotalSequenceLength() == 54
+    disk.close()
+
+
+def test_haplotype_from_variants():
+    from platypus_amd import chaplotype
+    ref = FastaFile(sequences={b"c": REF})
+    # padding by 2 * maxReadLength, clamped to the sequence (chaplotype.pyx:70-71)
+    h = chaplotype.Haplotype.fromVariants(b"c", 20, 30, (), ref, 4)
+    assert (h.startPosPy, h.endPosPy) == (12, 38) and h.sequence == REF[12:38] and h.varSeqLenPy == 0
+    h = chaplotype.Haplotype.fromVariants(b"c", 3, 45, (), ref, 4)
+    assert (h.startPosPy, h.endPosPy) == (0, 50) and h.sequence == REF[:49]   # getSequence cannot return the last base
+    snp = Variant(b"c", 10, b"G", b"T")
+    ins = Variant(b"c", 15, b"", b"GG")                 # after the base at 15
+    dele = Variant(b"c", 24, b"CC", b"")                # bases 25 and 26 go, 24 stays
+    h = chaplotype.Haplotype.fromVariants(b"c", 8, 30, (snp, ins, dele), ref, 1)
+    want = REF[6:10] + b"T" + REF[11:16] + b"GG" + REF[16:25] + REF[27:32]
+    assert h.sequence == want and h.varSeqLenPy == 4 and h.variantsPy() == (snp, ins, dele)
+    # a SNP and an insertion at the same position: the SNP replaces the base, the insertion follows it
+    snp15 = Variant(b"c", 15, b"T", b"A")
+    h = chaplotype.Haplotype.fromVariants(b"c", 8, 30, (snp15, ins), ref, 1)
+    assert h.sequence == REF[6:15] + b"A" + b"GG" + REF[16:32]
+    # a multi-nucleotide substitution
+    mnp = Variant(b"c", 20, b"AAA", b"CGC")
+    h = chaplotype.Haplotype.fromVariants(b"c", 18, 26, (mnp,), ref, 0)
+    assert h.sequence == REF[18:20] + b"CGC" + REF[23:26]
+    with pytest.raises(ValueError):
+        chaplotype.Haplotype.fromVariants(b"c", 8, 30, (Variant(b"c", 12, b"AC", b"G"),), ref, 1)
