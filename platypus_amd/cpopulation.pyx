@@ -395,6 +395,118 @@ cdef class WindowBatch:
         self.populations = out
         return out
 
+    def siteLikelihoods(self, list items):
+        """The second alignment site of the reference, batched: for every emitted single-variant
+        site the reference builds a fresh reference haplotype and a fresh variant haplotype and
+        computes, per individual, the log-likelihoods of the genotypes AA, AB, BB over the
+        window's reads (variantcaller.pyx:371-378,422-427).  `items` is a list of
+        (window index, refHap, varHap); all of them are aligned in ONE launch and summed in ONE
+        kernel.  Returns, per item, a list over individuals of (AA, AB, BB) -- unrounded; the
+        reference rounds to two decimals -- or None for an individual without reads.
+        The genotype/EM results of `run` stay valid."""
+        cdef pg_ctx* ctx = deviceContext()
+        cdef int nItems = len(items), it, i, w, n, k
+        cdef int64_t hapBytes = 0, readBytes = 0, nReadTot = 0, nRows = 0, ri = 0, row = 0
+        cdef Haplotype hap
+        cdef cAlignedRead* rd
+        cdef size_t p
+        cdef dict readBase = {}
+        cdef list order = []
+        if nItems == 0:
+            return []
+        for w, refHap, varHap in items:
+            if w not in readBase:
+                readBase[w] = -1
+                order.append(w)
+            hap = refHap
+            hapBytes += hap.hapLen
+            hap = varHap
+            hapBytes += hap.hapLen
+            nRows += 3 * len(self.windows[w][1])
+        for w in order:
+            for lst in self.windows[w][3]:
+                nReadTot += len(lst)
+                for q in lst:
+                    p = q
+                    readBytes += (<cAlignedRead*>p).rlen
+        cdef int64_t* hoff = <int64_t*>malloc((2 * nItems + 1) * sizeof(int64_t))
+        cdef int32_t* hstart = <int32_t*>malloc((2 * nItems + 1) * sizeof(int32_t))
+        cdef int32_t* hvl = <int32_t*>malloc((2 * nItems + 1) * sizeof(int32_t))
+        cdef char* hbuf = <char*>malloc(hapBytes + 1)
+        cdef int64_t* roff = <int64_t*>malloc((nReadTot + 1) * sizeof(int64_t))
+        cdef int32_t* rpos = <int32_t*>malloc((nReadTot + 1) * sizeof(int32_t))
+        cdef int32_t* rmq = <int32_t*>malloc((nReadTot + 1) * sizeof(int32_t))
+        cdef char* sbuf = <char*>malloc(readBytes + 1)
+        cdef char* qbuf = <char*>malloc(readBytes + 1)
+        cdef int32_t* b_hlo = <int32_t*>malloc((nItems + 1) * sizeof(int32_t))
+        cdef int32_t* b_nh = <int32_t*>malloc((nItems + 1) * sizeof(int32_t))
+        cdef int32_t* b_rlo = <int32_t*>malloc((nItems + 1) * sizeof(int32_t))
+        cdef int32_t* b_nr = <int32_t*>malloc((nItems + 1) * sizeof(int32_t))
+        cdef int64_t* base = <int64_t*>malloc((nItems + 1) * sizeof(int64_t))
+        cdef int64_t* g1 = <int64_t*>malloc((nRows + 1) * sizeof(int64_t))
+        cdef int64_t* g2 = <int64_t*>malloc((nRows + 1) * sizeof(int64_t))
+        cdef int32_t* gn = <int32_t*>malloc((nRows + 1) * sizeof(int32_t))
+        cdef double* gout = <double*>malloc((nRows + 1) * sizeof(double))
+        cdef int64_t bRef, bVar
+        cdef list out = []
+        try:
+            roff[0] = 0
+            for w in order:                                       # reads of every window involved, once
+                readBase[w] = ri
+                for lst in self.windows[w][3]:
+                    for q in lst:
+                        p = q
+                        rd = <cAlignedRead*>p
+                        memcpy(sbuf + roff[ri], rd.seq, rd.rlen)
+                        memcpy(qbuf + roff[ri], rd.qual, rd.rlen)
+                        roff[ri + 1] = roff[ri] + rd.rlen
+                        rpos[ri] = rd.pos
+                        rmq[ri] = rd.mapq
+                        ri += 1
+            hoff[0] = 0
+            for it in range(nItems):
+                w, refHap, varHap = items[it]
+                for k, hp in enumerate((refHap, varHap)):
+                    hap = hp
+                    memcpy(hbuf + hoff[2 * it + k], hap.cHaplotypeSequence, hap.hapLen)
+                    hoff[2 * it + k + 1] = hoff[2 * it + k] + hap.hapLen
+                    hstart[2 * it + k] = hap.startPos
+                    hvl[2 * it + k] = hap.varSeqLen
+                b_hlo[it] = 2 * it
+                b_nh[it] = 2
+                b_rlo[it] = <int32_t>readBase[w]
+                b_nr[it] = sum(self.windows[w][2])
+            hap = items[0][1]
+            setParams(hap.cHomopolQ, 3, 2)
+            check(ctx, pg_haps_upload(ctx, 2 * nItems, hbuf, hoff, hstart, hvl))
+            check(ctx, pg_reads_upload(ctx, <int>nReadTot, sbuf, qbuf, roff, rpos, rmq))
+            check(ctx, pg_pairs_blocks(ctx, nItems, b_hlo, b_nh, b_rlo, b_nr, base))
+            check(ctx, pg_align_launch(ctx))
+            for it in range(nItems):
+                w = items[it][0]
+                n = 0
+                for cnt in self.windows[w][2]:
+                    bRef = base[it] + n
+                    bVar = base[it] + b_nr[it] + n
+                    g1[row] = bRef; g2[row] = bRef; gn[row] = cnt          # AA
+                    g1[row + 1] = bRef; g2[row + 1] = bVar; gn[row + 1] = cnt  # AB
+                    g1[row + 2] = bVar; g2[row + 2] = bVar; gn[row + 2] = cnt  # BB
+                    row += 3
+                    n += <int>cnt
+            check(ctx, pg_genotype_loglik(ctx, nRows, g1, g2, gn, gout))
+            row = 0
+            for it in range(nItems):
+                w = items[it][0]
+                res = []
+                for cnt in self.windows[w][2]:
+                    res.append((gout[row], gout[row + 1], gout[row + 2]) if cnt > 0 else None)
+                    row += 3
+                out.append(res)
+        finally:
+            free(hoff); free(hstart); free(hvl); free(hbuf); free(roff); free(rpos); free(rmq); free(sbuf); free(qbuf)
+            free(b_hlo); free(b_nh); free(b_rlo); free(b_nr); free(base); free(g1); free(g2); free(gn); free(gout)
+        return out
+
     def posteriors(self, list items):
         """[(window index, variant), ...] -> posteriors (cpopulation.pyx:515-632), one device call."""
         cdef pg_ctx* ctx = deviceContext()

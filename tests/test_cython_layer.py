@@ -248,3 +248,83 @@ def test_window_batch_equals_window_by_window():
     with pytest.raises(calign.PlatGpuError):
         pops[0].calculatePosteriorPy(wins[0][2][1])
     calign.closeDevice()
+
+
+@pytest.mark.gpu
+def test_site_likelihoods_second_alignment_site():
+    """WindowBatch.siteLikelihoods: AA/AB/BB log-likelihoods of fresh reference/variant haplotypes over a
+    window's reads (variantcaller.pyx:371-378,422-427), all sites in one launch, against the CPU checker."""
+    from oracle import pyoracle as po
+    from platypus_amd import calign, chaplotype, cpopulation
+    from platypus_amd.fastafile import FastaFile
+    from platypus_amd.variant import Variant
+    rng = np.random.default_rng(91)
+    L, G = 60, 4000
+    genome = bytes(b"ACGT"[i] for i in rng.integers(0, 4, G))
+    ref = FastaFile(sequences={b"c": genome})
+    batch = cpopulation.WindowBatch()
+    items, expected = [], []
+    for w in range(6):
+        ws = 400 + 500 * w
+        var = [Variant(b"c", ws + 20, genome[ws + 20:ws + 21], b"A" if genome[ws + 20:ws + 21] != b"A" else b"C"),
+               Variant(b"c", ws + 20, b"", b"GTG"),
+               Variant(b"c", ws + 20, genome[ws + 21:ws + 23], b"")][w % 3]
+        refHap = chaplotype.Haplotype.fromVariants(b"c", ws, ws + 40, (), ref, L)
+        varHap = chaplotype.Haplotype.fromVariants(b"c", ws, ws + 40, (var,), ref, L)
+        # reads sampled from either haplotype, two individuals (the second one empty in window 4)
+        seqs, quals, poss = [], [], []
+        for r in range(24):
+            src = (refHap, varHap)[r % 2].sequence
+            o = int(rng.integers(2 * L - 50, 2 * L - 5))
+            s = bytearray(src[o:o + L])
+            for j in np.flatnonzero(rng.random(L) < 0.02):
+                s[j] = b"ACGT"[int(rng.integers(0, 4))]
+            seqs.append(bytes(s)); quals.append(bytes(rng.integers(10, 41, L).astype(np.uint8)))
+            poss.append(refHap.startPosPy + o)
+        order = np.argsort(poss, kind="stable")
+        def make_buffer(ids):
+            from platypus_amd import cwindow
+            if len(ids) == 0:
+                z = np.zeros(0, np.int32)
+                return cwindow.bamReadBuffer(b"c", 0, 10, np.zeros(0, np.uint8), np.zeros(0, np.uint8),
+                                             np.zeros(1, np.int64), z, z, z)
+            seq = np.frombuffer(b"".join(seqs[i] for i in ids), dtype=np.uint8)
+            qual = np.frombuffer(b"".join(quals[i] for i in ids), dtype=np.uint8)
+            pos = np.array([poss[i] for i in ids], dtype=np.int32)
+            buf = cwindow.bamReadBuffer(b"c", int(pos.min()), int(pos.max()) + 100, seq, qual,
+                                        np.arange(len(ids) + 1, dtype=np.int64) * L, pos, pos + L,
+                                        np.full(len(ids), 50, np.int32))
+            buf.setWindow(int(pos.min()), int(pos.max()) + 1)
+            return buf
+        groups = [list(order[:14]), [] if w == 4 else list(order[14:])]
+        bufs = [make_buffer(g) for g in groups]
+        batch.add([refHap, varHap], bufs)
+        items.append((w, refHap, varHap))
+        exp = []
+        for g in groups:
+            if not g:
+                exp.append(None)
+                continue
+            rows = []
+            for hp in (refHap, varHap):
+                row = []
+                for i in g:
+                    sc, _ = po.align_no_traceback(seqs[i], quals[i], poss[i], hp.sequence, hp.startPosPy,
+                                                  hp.varSeqLenPy)
+                    row.append(po.likelihood(sc, 50))
+                rows.append(np.array(row))
+            exp.append((po.genotype_loglik(rows[0], rows[0]), po.genotype_loglik(rows[0], rows[1]),
+                        po.genotype_loglik(rows[1], rows[1])))
+        expected.append(exp)
+    pops = batch.run()
+    got = batch.siteLikelihoods(items)
+    for g_item, e_item in zip(got, expected):
+        assert len(g_item) == 2
+        for g, e in zip(g_item, e_item):
+            if e is None:
+                assert g is None
+            else:
+                np.testing.assert_allclose(g, e, rtol=1e-9)
+    # the genotype/EM results of run() are still reachable
+    assert 0.0 <= pops[0].calculatePosteriorPy(items[0][2].variantsPy()[0]) <= 1.0
+    calign.closeDevice()
