@@ -176,6 +176,22 @@ def main():
         "hbm_algorithmic_bytes": float(n_pairs) * (2 * L + 24),
     }
 
+    # ---- the consumer of the likelihood matrix (genotype likelihoods + EM per window), not part of
+    # the metric: kernel times of one pass over the same batch, one individual per window -----------
+    caller = None
+    try:
+        ctx.launch()
+        ctx.upload_windows([H] * n_windows, [1] * n_windows, np.arange(n_windows, dtype=np.int64) * H * R,
+                           np.tile(np.array([0, R], dtype=np.int32), n_windows))
+        ctx.caller_launch(100)
+        ctx.sync()
+        res = ctx.caller_fetch(genotype_post=False)
+        caller = {"windows": n_windows, "haplotypes": H, "individuals": 1,
+                  "setup_ms": ctx.kernel_ms(native.PG_K_CALLER_SETUP), "em_ms": ctx.kernel_ms(native.PG_K_CALLER_EM),
+                  "em_iterations_mean": float(res["iters"].mean()), "em_iterations_max": int(res["iters"].max())}
+    except native.PlatGpuError as e:                       # reported, never hidden
+        caller = {"error": str(e)}
+
     # ---- CPU baseline: the reference's own compiled routine on the host cores ---------
     cpu = None
     if not args.no_cpu:
@@ -211,6 +227,7 @@ def main():
         "pairs_per_s": float(n_pairs) * world * args.steps / dt,
         "roofline": roofline,
         "cpu_baseline": cpu,
+        "caller_stage": caller,
     }
     print(json.dumps(out), flush=True)
     ctx.close()

@@ -90,6 +90,12 @@ def test_many_haplotypes_many_individuals():
     run_case(n_windows=3, H=70, R=240, n_ind=20, seed=13, indel_frac=0.2)
 
 
+@pytest.mark.parametrize("H", [100, 130, 257])
+def test_wide_windows_all_column_chunk_shapes(H):
+    """haplotype counts that exercise 2, 3 and 4 + 1 column chunks of the EM's matrix-vector product"""
+    run_case(n_windows=2, H=H, R=36, n_ind=3, seed=30 + H, indel_frac=0.1, read_len=40, hap_len=200)
+
+
 def test_two_haplotypes():
     run_case(n_windows=40, H=2, R=16, n_ind=2, seed=14)
 
