@@ -330,6 +330,155 @@ __global__ __launch_bounds__(1024) void k_vote2(const uint32_t* __restrict__ hap
 }
 
 // ---------------------------------------------------------------------------
+// k_vote4: the same anchoring with four LANES per read.  The reference's
+// winner, the first position to reach the final maximum count
+// (platypus/calign.pyx:148-155), is decided without counters whenever one
+// position holds more than half of all votes: that position is the only
+// maximum, so it wins whatever the order.  Two candidates are tried: the
+// position named by the first vote among the read's first eight 7-mers and the
+// one named by the last vote among its last eight (a read that carries an indel
+// relative to this haplotype splits its votes between two positions; the
+// larger group is one of these).  The four lanes of a read take its 16-base
+// groups in turn and count the votes for the two candidates -- per 7-mer a
+// shift, a mask, one LDS look-up and a few ALU instructions, an order of
+// magnitude fewer instructions per read than mapping a read with a whole
+// wavefront -- and add their counts with quad shuffles.  Reads in which neither
+// candidate holds a majority (few) are then mapped one by one by the wavefront
+// with the counting sweeps of vote_read.
+// LDS: table (32 KiB) | per wavefront: counters u16[cnt_stride] | packed read u32[row_words].
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int quad_sum(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_vote4(const uint32_t* __restrict__ hap2,
+                                               const int64_t* __restrict__ hap2off,
+                                               const int32_t* __restrict__ hap_len,
+                                               const uint32_t* __restrict__ read2,
+                                               const int32_t* __restrict__ vh_list,
+                                               const int64_t* __restrict__ vh_ptr,
+                                               const VoteRec* __restrict__ vh_recs,
+                                               int32_t* __restrict__ anchor, int cnt_stride, int row_words)
+{
+    extern __shared__ uint32_t lds[];
+    uint16_t* tab = reinterpret_cast<uint16_t*>(lds);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_thr = blockDim.x, n_wav = n_thr >> 6;
+    const int part = tid & 3, slot = tid >> 2, n_slots = n_thr >> 2;      // four lanes per read
+    uint16_t* cnt16 = tab + kHashSize + wave * cnt_stride;
+    uint32_t* cnt32 = reinterpret_cast<uint32_t*>(cnt16);
+    uint32_t* row = lds + (kHashSize + n_wav * cnt_stride) / 2 + wave * row_words;
+    const int h = vh_list[blockIdx.x];
+    const uint32_t* hw = hap2 + hap2off[h];
+    const int L = hap_len[h];
+    const int64_t q0 = vh_ptr[blockIdx.x], q_end = vh_ptr[blockIdx.x + 1];
+
+    // the first record of every read slot is fetched before the table is built
+    VoteRec rec = {0, 0, 0};
+    if (q0 + slot < q_end) rec = vh_recs[q0 + slot];
+
+    {   // table and counters start at zero (platypus/calign.pyx:105)
+        const int total_dw = (kHashSize + n_wav * cnt_stride) / 2;
+        uint4* z = reinterpret_cast<uint4*>(lds);
+        for (int i = tid; i < (total_dw >> 2); i += n_thr) z[i] = make_uint4(0, 0, 0, 0);
+        for (int i = (total_dw & ~3) + tid; i < total_dw; i += n_thr) lds[i] = 0;
+    }
+    __syncthreads();
+    const int nk = L - kHashNucs;               // last 7-mer is left out, calign.pyx:114
+    for (int i = tid; i < nk; i += n_thr) tab[hash7_packed(hw, i)] = (uint16_t)(i + 1);
+    __syncthreads();
+    for (int i = tid; i < nk; i += n_thr) {
+        const uint32_t k = hash7_packed(hw, i);
+        if (tab[k] != (uint16_t)(i + 1)) tab[k] = 0xffffu;   // some other start owns the slot: repeated
+    }
+    __syncthreads();
+
+    for (int64_t qb = q0; qb < q_end; qb += n_slots) {
+        const bool mine = qb + slot < q_end;
+        if (qb > q0) rec = mine ? vh_recs[qb + slot] : VoteRec{0, 0, 0};
+        const int rl = rec.rlen;
+        const int nv = mine && rl > kHashNucs ? rl - kHashNucs : 0;            // calign.pyx:143
+        const uint32_t* rw = read2 + rec.r2off;
+        const int n_groups = (nv + 15) >> 4;
+
+        // candidates: lane 0 of the quad looks at the first eight 7-mers, lane 1 at the last eight
+        int c = 0x40000000;                                                      // matches no position
+        if (part < 2 && nv > 0) {
+            int pvs[8], idx[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                idx[t] = part == 0 ? t : nv - 1 - t;
+                const bool in = idx[t] >= 0 && idx[t] < nv;
+                pvs[t] = in ? (int)(int16_t)tab[hash7_packed(rw, in ? idx[t] : 0)] : 0;
+            }
+            bool found = false;
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                if (!found && pvs[t] > 0) { c = pvs[t] - 1 - idx[t]; found = true; }
+        }
+        const int c1 = __builtin_amdgcn_update_dpp(0, c, 0x00, 0xf, 0xf, false);   // quad_perm [0,0,0,0]
+        const int c2 = __builtin_amdgcn_update_dpp(0, c, 0x55, 0xf, 0xf, false);   // quad_perm [1,1,1,1]
+
+        // counts over this lane's 16-base groups: part, part + 4, ...
+        int total = 0, n1 = 0, n2 = 0;
+        uint2 ww = make_uint2(0, 0);
+        if (part < n_groups) __builtin_memcpy(&ww, rw + part, 8);
+        for (int g = part; g < n_groups; g += 4) {
+            const uint2 w = ww;
+            if (g + 4 < n_groups) __builtin_memcpy(&ww, rw + g + 4, 8);         // next group's words
+            int pv[16];                               // all 16 look-ups first: they are independent
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const uint32_t hsh = (j == 0 ? w.x : __builtin_amdgcn_alignbit(w.y, w.x, 2 * j)) & 0x3fffu;
+                pv[j] = (int16_t)tab[hsh];
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int i = 16 * g + j;
+                const bool valid = pv[j] > 0 && i < nv;              // 0 absent, 0xffff (= -1) repeated
+                const int pos = pv[j] - 1 - i;                       // calign.pyx:144-147
+                total += valid;
+                n1 += valid && pos == c1;
+                n2 += valid && pos == c2;
+            }
+        }
+        total = quad_sum(total); n1 = quad_sum(n1); n2 = quad_sum(n2);
+        int winner = 0;                                               // calign.pyx:137: nothing votes
+        bool undecided = false;
+        if (total > 0) {
+            if (2 * n1 > total) winner = c1;
+            else if (2 * n2 > total) winner = c2;
+            else undecided = true;
+        }
+        if (mine && part == 0 && !undecided) anchor[rec.pair] = winner - 8 > 0 ? winner - 8 : 0;   // calign.pyx:67
+
+        // reads without a majority position: the wavefront maps them one at a time
+        unsigned long long todo = __ballot(undecided && part == 0);
+        while (todo) {
+            const int j = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int pair = __builtin_amdgcn_readlane(rec.pair, j);
+            const int rlj = __builtin_amdgcn_readlane(rec.rlen, j);
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rec.r2off, j);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)rec.r2off >> 32), j);
+            const int64_t r2 = (int64_t)(((uint64_t)hi << 32) | lo);
+            const int nw = (rlj + 15) / 16 + 1;
+            for (int w = lane; w < nw; w += 64) row[w] = read2[r2 + w];
+            __builtin_amdgcn_wave_barrier();
+            const int nvj = rlj - kHashNucs;
+            const int n_chunks = nvj > 0 ? (nvj + 63) >> 6 : 0;
+            int win;
+            if (n_chunks <= 4) win = vote_read<true>(tab, row, cnt16, cnt32, rlj, nvj, n_chunks, lane);
+            else               win = vote_read<false>(tab, row, cnt16, cnt32, rlj, nvj, n_chunks, lane);
+            if (lane == 0) anchor[pair] = win - 8 > 0 ? win - 8 : 0;
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // k_genotype: out[g] = sum_r log(0.5*(L[b1+r] + L[b2+r])), read order
 // (platypus/cgenotype.pyx:58-61).  One wavefront per genotype row: lanes take
 // reads r = lane, lane+64, ...; partial sums are combined in a fixed tree, so

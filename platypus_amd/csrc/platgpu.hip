@@ -50,7 +50,7 @@ struct pg_ctx {
     int gapextend = 3, nucprior = 2;
     std::string table;
     DevBuf<uint8_t> d_tab1;              // table[h] - 33
-    int vote_waves = 8;                  // PG_VOTE_WAVES: wavefronts per workgroup of the vote kernel (experiments)
+    int vote_waves = 0;                  // PG_VOTE_WAVES: wavefronts per workgroup of the vote kernel (experiments; 0 = default)
     int lds_pad = 0;                     // PG_ALIGN_LDS_PAD: extra LDS per workgroup, to lower occupancy in experiments
     DevBuf<double> d_exp_score, d_exp_mapq;
 
@@ -508,16 +508,27 @@ int pg_align_launch(pg_ctx* c) {
         cnt_stride += cnt_stride & 1;
         // as many reads in flight per haplotype as LDS allows, two workgroups per CU if possible
         const int row_words = (c->max_rlen + 15) / 16 + 2;
-        int n_wav = c->vote_waves;
+        // four lanes per read (k_vote4, four wavefronts per haplotype) unless PG_VOTE_KERNEL=2 asks for
+        // the one-wavefront-per-read kernel (experiments)
+        const char* vk = std::getenv("PG_VOTE_KERNEL");
+        const bool lane_per_read = !(vk && vk[0] == '2');
+        int n_wav = c->vote_waves > 0 ? c->vote_waves : (lane_per_read ? 4 : 8);
         auto lds_bytes = [&](int w) { return (size_t)pg::kHashSize * 2 + (size_t)w * (cnt_stride * 2 + row_words * 4); };
         while (n_wav > 1 && lds_bytes(n_wav) > 160 * 1024) n_wav >>= 1;
         const size_t lds = lds_bytes(n_wav);
         if (lds > 160 * 1024)
             return fail(c, PG_ERR_UNSUPPORTED, "vote counters for haplotype length %d need %zu bytes of LDS", c->max_hap_len, lds);
-        PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_vote2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(pg::k_vote2, dim3(c->n_vote_haps), dim3(64 * n_wav), lds, c->stream, c->d_hap2.p,
-                           c->d_hap2off.p, c->d_hap_len.p, c->d_read2.p, c->d_vh_list.p, c->d_vh_ptr.p,
-                           c->d_vh_recs.p, c->d_anchor_in.p, cnt_stride, row_words);
+        if (lane_per_read) {
+            PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_vote4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(pg::k_vote4, dim3(c->n_vote_haps), dim3(64 * std::min(n_wav, 4)), lds, c->stream, c->d_hap2.p,
+                               c->d_hap2off.p, c->d_hap_len.p, c->d_read2.p, c->d_vh_list.p, c->d_vh_ptr.p,
+                               c->d_vh_recs.p, c->d_anchor_in.p, cnt_stride, row_words);
+        } else {
+            PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_vote2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(pg::k_vote2, dim3(c->n_vote_haps), dim3(64 * n_wav), lds, c->stream, c->d_hap2.p,
+                               c->d_hap2off.p, c->d_hap_len.p, c->d_read2.p, c->d_vh_list.p, c->d_vh_ptr.p,
+                               c->d_vh_recs.p, c->d_anchor_in.p, cnt_stride, row_words);
+        }
         PG_HIP(c, hipGetLastError());
     }
     PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_ANCHOR + 1], c->stream));
