@@ -1,7 +1,7 @@
 // Device kernels of libplatgpu (gfx950 only), all but the banded DP (pg_align.hip.h).
 //
 //   k_pack_codes  upload pass: 2-bit packed bases of haplotypes and reads
-//   k_vote2       7-mer anchoring (hash_sequence + map_read of the reference)
+//   k_vote4       7-mer anchoring (hash_sequence + map_read of the reference)
 //   k_genotype    per-genotype log-likelihood sums
 //   k_pk_rate     issue-rate probe of the packed int16 VALU instructions
 #pragma once
@@ -79,18 +79,22 @@ __device__ __forceinline__ uint32_t hash7_packed(const uint32_t* __restrict__ ro
     return (uint32_t)(v >> (2 * (i & 15))) & 0x3fffu;
 }
 
-struct VoteRec {      // one (read, indel haplotype) pair of k_vote2, built on the host
+struct VoteHap {      // one indel-bearing haplotype of k_vote4 and its records [q0, q1)
+    int32_t hap, len;
+    int64_t hap2off;  // word offset of the haplotype's packed row
+    int64_t q0, q1;
+};
+
+struct VoteRec {      // one (read, indel haplotype) pair of k_vote4, built on the host
     int32_t pair;     // index into the pair list
     int32_t rlen;     // read length
     int64_t r2off;    // word offset of the read's packed row
 };
 
 // ---------------------------------------------------------------------------
-// k_vote2: one workgroup per indel-bearing haplotype, blockDim.x / 64 reads in
-// flight.  The unique-7-mer table of platypus/calign.pyx:99-123 is built once
-// per haplotype in LDS (16384 x u16: 0 absent, i+1 unique start, 0xffff
-// repeated) instead of once per read.  A wavefront maps one read at a time
-// (platypus/calign.pyx:126-158) in three sweeps over its votes, none of which
+// vote_read: one wavefront maps one read against the unique-7-mer table of a
+// haplotype in LDS (16384 x u16: 0 absent, i+1 unique start, 0xffff repeated;
+// platypus/calign.pyx:99-158) in three sweeps over its votes, none of which
 // depends on the order in which lanes reach LDS:
 //   A  atomic +1 on the vote counter of every hit position
 //   B  maximum final count
@@ -98,10 +102,8 @@ struct VoteRec {      // one (read, indel haplotype) pair of k_vote2, built on t
 //      its LAST vote -- the vote that brought it to the maximum; the reference's
 //      winner, the first position to reach the final maximum, is therefore the
 //      one met last.  Counters are cleared on the way.
-// The kernel is latency bound (a few reads per haplotype), so each wavefront
-// fetches its first read before the table is built, keeps the packed read in a
-// private LDS row for the three sweeps, and fetches the next read meanwhile.
-// LDS: table (32 KiB) | per wavefront: counters u16[cnt_stride] | packed read u32[row_words].
+// The packed read sits in a private LDS row of the wavefront.  k_vote4 uses it
+// for the reads its majority test cannot decide.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t hash7_lds(const uint32_t* row, int i) {
     const uint32_t w0 = row[i >> 4], w1 = row[(i >> 4) + 1];
@@ -236,99 +238,6 @@ __device__ __forceinline__ int vote_read(const uint16_t* tab, const uint32_t* ro
     return winner;
 }
 
-__global__ __launch_bounds__(1024) void k_vote2(const uint32_t* __restrict__ hap2,
-                                                const int64_t* __restrict__ hap2off,
-                                                const int32_t* __restrict__ hap_len,
-                                                const uint32_t* __restrict__ read2,
-                                                const int32_t* __restrict__ vh_list,
-                                                const int64_t* __restrict__ vh_ptr,
-                                                const VoteRec* __restrict__ vh_recs,
-                                                int32_t* __restrict__ anchor, int cnt_stride, int row_words)
-{
-    extern __shared__ uint32_t lds[];
-    uint16_t* tab = reinterpret_cast<uint16_t*>(lds);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n_thr = blockDim.x, n_wav = n_thr >> 6;
-    uint16_t* cnt16 = tab + kHashSize + wave * cnt_stride;
-    uint32_t* cnt32 = reinterpret_cast<uint32_t*>(cnt16);
-    uint32_t* row = lds + (kHashSize + n_wav * cnt_stride) / 2 + wave * row_words;
-    const int h = vh_list[blockIdx.x];
-    const uint32_t* hw = hap2 + hap2off[h];
-    const int L = hap_len[h];
-    const int64_t q_end = vh_ptr[blockIdx.x + 1];
-    int64_t q = vh_ptr[blockIdx.x] + wave;
-
-    // This wavefront's reads are q, q + n_wav, ...  Lane j fetches the record of the j-th of
-    // them (64 per batch), and the packed rows of the next four reads are always in flight:
-    // the loop below never waits for a record -> row chain of two dependent global loads.
-    const int64_t n_mine = q < q_end ? (q_end - q + n_wav - 1) / n_wav : 0;
-    VoteRec lrec = {0, 0, 0};
-    if (lane < n_mine) lrec = vh_recs[q + (int64_t)lane * n_wav];
-    uint32_t wf[4] = {0, 0, 0, 0};
-    auto rec_of = [&](int j, int& pair, int& rl, int64_t& r2) {
-        pair = __builtin_amdgcn_readlane(lrec.pair, j);
-        rl = __builtin_amdgcn_readlane(lrec.rlen, j);
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)lrec.r2off, j);
-        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)lrec.r2off >> 32), j);
-        r2 = (int64_t)(((uint64_t)hi << 32) | lo);
-    };
-    auto fetch_row = [&](int j, int nb) -> uint32_t {
-        if (j >= nb) return 0;
-        int pair, rl; int64_t r2;
-        rec_of(j, pair, rl, r2);
-        return lane < (rl + 15) / 16 + 1 ? read2[r2 + lane] : 0u;
-    };
-    {
-        const int nb0 = n_mine < 64 ? (int)n_mine : 64;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) wf[k] = fetch_row(k, nb0);
-    }
-
-    const int total_dw = (kHashSize + n_wav * cnt_stride) / 2;
-    for (int i = tid; i < total_dw; i += n_thr) lds[i] = 0;
-    __syncthreads();
-    const int nk = L - kHashNucs;               // last 7-mer is left out, calign.pyx:114
-    for (int i = tid; i < nk; i += n_thr) tab[hash7_packed(hw, i)] = (uint16_t)(i + 1);
-    __syncthreads();
-    for (int i = tid; i < nk; i += n_thr) {
-        const uint32_t k = hash7_packed(hw, i);
-        if (tab[k] != (uint16_t)(i + 1)) tab[k] = 0xffffu;   // some other start owns the slot: repeated
-    }
-    __syncthreads();
-
-    for (int64_t b0 = 0; b0 < n_mine; b0 += 64) {
-        const int nb = n_mine - b0 < 64 ? (int)(n_mine - b0) : 64;
-        if (b0 > 0) {                            // next batch of records and its first four rows
-            lrec = lane < nb ? vh_recs[q + (b0 + lane) * n_wav] : VoteRec{0, 0, 0};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) wf[k] = fetch_row(k, nb);
-        }
-        for (int j0 = 0; j0 < nb; j0 += 4) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int j = j0 + k;
-                if (j < nb) {
-                    int pair, rl; int64_t r2;
-                    rec_of(j, pair, rl, r2);
-                    const int n_words = (rl + 15) / 16 + 1;
-                    // packed read into the wavefront's LDS row
-                    if (lane < n_words) row[lane] = wf[k];
-                    for (int w = 64 + lane; w < n_words; w += 64) row[w] = read2[r2 + w];
-                    __builtin_amdgcn_wave_barrier();
-                    wf[k] = fetch_row(j + 4, nb);    // the read four places on
-                    const int nv = rl - kHashNucs;   // calign.pyx:143
-                    const int n_chunks = nv > 0 ? (nv + 63) >> 6 : 0;
-                    int winner;
-                    if (n_chunks <= 4) winner = vote_read<true>(tab, row, cnt16, cnt32, rl, nv, n_chunks, lane);
-                    else               winner = vote_read<false>(tab, row, cnt16, cnt32, rl, nv, n_chunks, lane);
-                    if (lane == 0) anchor[pair] = winner - 8 > 0 ? winner - 8 : 0;   // calign.pyx:67
-                    __builtin_amdgcn_wave_barrier();
-                }
-            }
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------
 // k_vote4: the same anchoring with four LANES per read.  The reference's
 // winner, the first position to reach the final maximum count
@@ -354,11 +263,8 @@ __device__ __forceinline__ int quad_sum(int v) {
 }
 
 __global__ __launch_bounds__(256) void k_vote4(const uint32_t* __restrict__ hap2,
-                                               const int64_t* __restrict__ hap2off,
-                                               const int32_t* __restrict__ hap_len,
                                                const uint32_t* __restrict__ read2,
-                                               const int32_t* __restrict__ vh_list,
-                                               const int64_t* __restrict__ vh_ptr,
+                                               const VoteHap* __restrict__ vh,
                                                const VoteRec* __restrict__ vh_recs,
                                                int32_t* __restrict__ anchor, int cnt_stride, int row_words)
 {
@@ -370,14 +276,19 @@ __global__ __launch_bounds__(256) void k_vote4(const uint32_t* __restrict__ hap2
     uint16_t* cnt16 = tab + kHashSize + wave * cnt_stride;
     uint32_t* cnt32 = reinterpret_cast<uint32_t*>(cnt16);
     uint32_t* row = lds + (kHashSize + n_wav * cnt_stride) / 2 + wave * row_words;
-    const int h = vh_list[blockIdx.x];
-    const uint32_t* hw = hap2 + hap2off[h];
-    const int L = hap_len[h];
-    const int64_t q0 = vh_ptr[blockIdx.x], q_end = vh_ptr[blockIdx.x + 1];
+    const VoteHap H = vh[blockIdx.x];                 // one 32-byte descriptor: no chain of dependent loads
+    const uint32_t* hw = hap2 + H.hap2off;
+    const int L = H.len;
+    const int64_t q0 = H.q0, q_end = H.q1;
 
-    // the first record of every read slot is fetched before the table is built
+    // the first record of every read slot and this thread's first four 7-mers of the haplotype
+    // are fetched before the table is cleared
     VoteRec rec = {0, 0, 0};
     if (q0 + slot < q_end) rec = vh_recs[q0 + slot];
+    const int nk = L - kHashNucs;               // last 7-mer is left out, calign.pyx:114
+    uint32_t hk[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) { const int i = tid + m * n_thr; hk[m] = i < nk ? hash7_packed(hw, i) : 0u; }
 
     {   // table and counters start at zero (platypus/calign.pyx:105)
         const int total_dw = (kHashSize + n_wav * cnt_stride) / 2;
@@ -386,12 +297,16 @@ __global__ __launch_bounds__(256) void k_vote4(const uint32_t* __restrict__ hap2
         for (int i = (total_dw & ~3) + tid; i < total_dw; i += n_thr) lds[i] = 0;
     }
     __syncthreads();
-    const int nk = L - kHashNucs;               // last 7-mer is left out, calign.pyx:114
-    for (int i = tid; i < nk; i += n_thr) tab[hash7_packed(hw, i)] = (uint16_t)(i + 1);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) { const int i = tid + m * n_thr; if (i < nk) tab[hk[m]] = (uint16_t)(i + 1); }
+    for (int i = tid + 4 * n_thr; i < nk; i += n_thr) tab[hash7_packed(hw, i)] = (uint16_t)(i + 1);
     __syncthreads();
-    for (int i = tid; i < nk; i += n_thr) {
+    // some other start owns the slot: the 7-mer is repeated
+#pragma unroll
+    for (int m = 0; m < 4; ++m) { const int i = tid + m * n_thr; if (i < nk && tab[hk[m]] != (uint16_t)(i + 1)) tab[hk[m]] = 0xffffu; }
+    for (int i = tid + 4 * n_thr; i < nk; i += n_thr) {
         const uint32_t k = hash7_packed(hw, i);
-        if (tab[k] != (uint16_t)(i + 1)) tab[k] = 0xffffu;   // some other start owns the slot: repeated
+        if (tab[k] != (uint16_t)(i + 1)) tab[k] = 0xffffu;
     }
     __syncthreads();
 

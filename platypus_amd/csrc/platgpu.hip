@@ -70,7 +70,7 @@ struct pg_ctx {
     int n_reads = 0;
     int max_rlen = 0;
     bool uniform_rlen = true;
-    std::vector<int64_t> h_read_off, h_read2off;
+    std::vector<int64_t> h_read_off, h_read2off, h_hap2off;
     DevBuf<uint8_t> d_rseq, d_rqual;
     DevBuf<uint16_t> d_readx;
     DevBuf<int64_t> d_roff, d_read_xoff, d_read2off;
@@ -82,9 +82,9 @@ struct pg_ctx {
     int n_waves = 0;
     int n_vote_haps = 0;
     bool have_order = false;
-    DevBuf<int32_t> d_pair_hap, d_pair_read, d_order, d_vh_list, d_anchor_in;
+    DevBuf<int32_t> d_pair_hap, d_pair_read, d_order, d_anchor_in;
+    DevBuf<pg::VoteHap> d_vh;
     DevBuf<uint8_t> d_n_flag;
-    DevBuf<int64_t> d_vh_ptr;
     DevBuf<pg::WaveDesc> d_waves;
     DevBuf<pg::VoteRec> d_vh_recs;
 
@@ -212,7 +212,7 @@ int pg_ctx_destroy(pg_ctx* c) {
     c->d_rseq.release(); c->d_rqual.release(); c->d_roff.release();
     c->d_read_pos.release(); c->d_read_mapq.release(); c->d_flag.release();
     c->d_pair_hap.release(); c->d_pair_read.release(); c->d_order.release();
-    c->d_vh_list.release(); c->d_anchor_in.release(); c->d_vh_ptr.release();
+    c->d_vh.release(); c->d_anchor_in.release();
     c->d_n_flag.release(); c->d_wins.release(); c->d_ioff.release(); c->d_em_iters.release(); c->d_best_gen.release();
     c->d_var_win.release(); c->d_cells.release(); c->d_full.release(); c->d_freq.release(); c->d_em_change.release();
     c->d_best_val.release(); c->d_var_prior.release(); c->d_var_out.release(); c->d_var_moff.release(); c->d_win_max.release(); c->d_rows.release(); c->d_var_mask.release(); c->d_vh_recs.release(); c->d_waves.release(); c->d_score.release(); c->d_anchor.release(); c->d_like.release();
@@ -300,6 +300,7 @@ int pg_haps_upload(pg_ctx* c, int n, const char* seq, const int64_t* off,
     PG_HIP(c, hipGetLastError());
     PG_HIP(c, hipStreamSynchronize(c->stream));   // host vectors above go out of scope
     c->h_hap_off.assign(soff.begin(), soff.end());
+    c->h_hap2off.swap(off2);
     c->h_hap_varlen.assign(var_seq_len, var_seq_len + n);
     c->max_hap_len = maxlen;
     c->n_haps = n;
@@ -408,9 +409,9 @@ int pg_pairs_upload(pg_ctx* c, int64_t np, const int32_t* hap_idx, const int32_t
     }
 
     // ---- pairs on indel-bearing haplotypes, grouped by haplotype ---------------
-    std::vector<int32_t> vh_list, vh_pairs;
+    std::vector<int32_t> vh_pairs;
     std::vector<pg::VoteRec> vh_recs;
-    std::vector<int64_t> vh_ptr;
+    std::vector<pg::VoteHap> vh;
     {
         std::vector<int64_t> per_hap(c->n_haps + 1, 0);
         int64_t nv = 0;
@@ -429,11 +430,11 @@ int pg_pairs_upload(pg_ctx* c, int64_t np, const int32_t* hap_idx, const int32_t
                 vh_recs[i] = {vh_pairs[i], (int32_t)(c->h_read_off[r + 1] - c->h_read_off[r]), c->h_read2off[r]};
             }
             for (int h = 0; h < c->n_haps; ++h)
-                if (start[h + 1] > start[h]) { vh_list.push_back(h); vh_ptr.push_back(start[h]); }
-            vh_ptr.push_back(nv);
+                if (start[h + 1] > start[h])
+                    vh.push_back({h, (int32_t)(c->h_hap_off[h + 1] - c->h_hap_off[h]), c->h_hap2off[h], start[h], start[h + 1]});
         }
     }
-    c->n_vote_haps = (int)vh_list.size();
+    c->n_vote_haps = (int)vh.size();
 
     PG_HIP(c, c->d_pair_hap.reserve(np));
     PG_HIP(c, c->d_pair_read.reserve(np));
@@ -451,10 +452,8 @@ int pg_pairs_upload(pg_ctx* c, int64_t np, const int32_t* hap_idx, const int32_t
         PG_HIP(c, hipMemcpyAsync(c->d_order.p, order.data(), np * 4, hipMemcpyHostToDevice, c->stream));
     }
     if (c->n_vote_haps > 0) {
-        PG_HIP(c, c->d_vh_list.reserve(vh_list.size()));
-        PG_HIP(c, c->d_vh_ptr.reserve(vh_ptr.size()));
-        PG_HIP(c, hipMemcpyAsync(c->d_vh_list.p, vh_list.data(), vh_list.size() * 4, hipMemcpyHostToDevice, c->stream));
-        PG_HIP(c, hipMemcpyAsync(c->d_vh_ptr.p, vh_ptr.data(), vh_ptr.size() * 8, hipMemcpyHostToDevice, c->stream));
+        PG_HIP(c, c->d_vh.reserve(vh.size()));
+        PG_HIP(c, hipMemcpyAsync(c->d_vh.p, vh.data(), vh.size() * sizeof(pg::VoteHap), hipMemcpyHostToDevice, c->stream));
         PG_HIP(c, c->d_vh_recs.reserve(vh_recs.size()));
         PG_HIP(c, hipMemcpyAsync(c->d_vh_recs.p, vh_recs.data(), vh_recs.size() * sizeof(pg::VoteRec), hipMemcpyHostToDevice, c->stream));
     }
@@ -508,27 +507,16 @@ int pg_align_launch(pg_ctx* c) {
         cnt_stride += cnt_stride & 1;
         // as many reads in flight per haplotype as LDS allows, two workgroups per CU if possible
         const int row_words = (c->max_rlen + 15) / 16 + 2;
-        // four lanes per read (k_vote4, four wavefronts per haplotype) unless PG_VOTE_KERNEL=2 asks for
-        // the one-wavefront-per-read kernel (experiments)
-        const char* vk = std::getenv("PG_VOTE_KERNEL");
-        const bool lane_per_read = !(vk && vk[0] == '2');
-        int n_wav = c->vote_waves > 0 ? c->vote_waves : (lane_per_read ? 4 : 8);
+        // four lanes per read, four wavefronts per haplotype
+        int n_wav = c->vote_waves > 0 ? std::min(c->vote_waves, 4) : 4;
         auto lds_bytes = [&](int w) { return (size_t)pg::kHashSize * 2 + (size_t)w * (cnt_stride * 2 + row_words * 4); };
         while (n_wav > 1 && lds_bytes(n_wav) > 160 * 1024) n_wav >>= 1;
         const size_t lds = lds_bytes(n_wav);
         if (lds > 160 * 1024)
             return fail(c, PG_ERR_UNSUPPORTED, "vote counters for haplotype length %d need %zu bytes of LDS", c->max_hap_len, lds);
-        if (lane_per_read) {
-            PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_vote4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(pg::k_vote4, dim3(c->n_vote_haps), dim3(64 * std::min(n_wav, 4)), lds, c->stream, c->d_hap2.p,
-                               c->d_hap2off.p, c->d_hap_len.p, c->d_read2.p, c->d_vh_list.p, c->d_vh_ptr.p,
-                               c->d_vh_recs.p, c->d_anchor_in.p, cnt_stride, row_words);
-        } else {
-            PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_vote2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(pg::k_vote2, dim3(c->n_vote_haps), dim3(64 * n_wav), lds, c->stream, c->d_hap2.p,
-                               c->d_hap2off.p, c->d_hap_len.p, c->d_read2.p, c->d_vh_list.p, c->d_vh_ptr.p,
-                               c->d_vh_recs.p, c->d_anchor_in.p, cnt_stride, row_words);
-        }
+        PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_vote4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(pg::k_vote4, dim3(c->n_vote_haps), dim3(64 * n_wav), lds, c->stream, c->d_hap2.p,
+                           c->d_read2.p, c->d_vh.p, c->d_vh_recs.p, c->d_anchor_in.p, cnt_stride, row_words);
         PG_HIP(c, hipGetLastError());
     }
     PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_ANCHOR + 1], c->stream));
