@@ -13,6 +13,7 @@
 //                 n x n matrices, the layout the EM streams
 //   k_em          EM iterations and genotype calls, one workgroup per window
 //   k_em_small    the same for windows of at most 8 haplotypes, one wavefront per window
+//   k_em_init/step/update/calls  the same for few large windows, one launch pair per iteration
 //   k_var_post    posterior of a variant given the haplotypes that carry it
 //
 // Sums over reads run in read order like the reference's; sums over genotypes
@@ -368,6 +369,168 @@ __global__ __launch_bounds__(1024) void k_em(const WinDesc* __restrict__ wins,
     else
         em_window<false>(em_lds, s_red, &s_with_data, wins, ioff, full, max_iters, n_max,
                          freq_out, iters_out, change_out, best_gen, best_val);
+}
+
+// ---------------------------------------------------------------------------
+// The same EM for batches of few, large windows (many haplotypes x many
+// individuals), where one workgroup per window would leave most of the chip
+// idle: every iteration is a pair of launches.
+//   k_em_step    grid (window, group of four individuals): one wavefront per
+//                individual computes y = P_i f and stores the individual's share
+//                2 f_k y_k / csrSum_i of every haplotype's total
+//   k_em_update  grid (window): adds the shares in individual order, new
+//                frequencies, largest change, convergence flag
+//   k_em_calls   grid (window, group): genotype calls from the last iteration's
+//                old frequencies
+// Frequencies live in global memory between launches; a window that has
+// converged (or reached max_iters) makes its workgroups return at once, and
+// `active` counts the windows still running so that the host can stop launching.
+// ---------------------------------------------------------------------------
+struct EmState {
+    double* f;          // per haplotype: current frequencies (the final output)
+    double* f_prev;     // per haplotype: frequencies before the last update
+    double* share;      // per (individual, haplotype) of every window
+    int32_t* iters;     // per window
+    double* change;     // per window
+    int32_t* done;      // per window
+    int32_t* active;    // one counter
+    const int64_t* share_base;   // per window: offset into share
+};
+
+__global__ __launch_bounds__(256) void k_em_init(const WinDesc* __restrict__ wins, int n_win, EmState S)
+{
+    const int w = blockIdx.x;
+    const WinDesc W = wins[w];
+    for (int k = threadIdx.x; k < W.n_hap; k += 256) {
+        S.f[W.hap_base + k] = 1.0 / W.n_hap;                                 // cpopulation.pyx:753,763-764
+        S.f_prev[W.hap_base + k] = 1.0 / W.n_hap;
+    }
+    if (threadIdx.x == 0) {
+        double eps = 1.0 / (W.n_ind * 2 * 2);
+        eps = eps < 1e-3 ? eps : 1e-3;
+        S.iters[w] = 0; S.change[w] = eps + 1; S.done[w] = 0;                // cpopulation.pyx:751-752
+        if (w == 0) *S.active = n_win;
+    }
+}
+
+template <int MODE>   // 0: one EM step, 1: genotype calls
+__device__ __forceinline__ void em_individual(const WinDesc* __restrict__ wins, const int32_t* __restrict__ ioff,
+                                              const double* __restrict__ full, EmState S, int n_max,
+                                              int32_t* __restrict__ best_gen, double* __restrict__ best_val)
+{
+    extern __shared__ double em_lds[];
+    const int w = blockIdx.x;
+    if (MODE == 0 && S.done[w]) return;
+    const WinDesc W = wins[w];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = W.n_hap;
+    const int i = blockIdx.y * 4 + wave;
+    double* f = em_lds;
+    double* yv = em_lds + n_max + (size_t)wave * n_max;
+    const double* f_glob = (MODE == 0 ? S.f : S.f_prev) + W.hap_base;
+    for (int k = tid; k < n; k += 256) f[k] = f_glob[k];
+    __syncthreads();
+    if (i >= W.n_ind) return;
+    const int32_t* io = ioff + W.ioff_base;
+    const bool has_reads = io[i + 1] != io[i];
+    if (MODE == 1) {
+        if (!has_reads) {                                                    // cpopulation.pyx:777-780
+            if (lane == 0) { best_gen[W.ind_base + i] = -1; best_val[W.ind_base + i] = 0.0; }
+            return;
+        }
+        if (S.iters[w] == 0) {
+            if (lane == 0) { best_gen[W.ind_base + i] = 0; best_val[W.ind_base + i] = 0.0; }
+            return;
+        }
+    } else if (!has_reads) return;                                           // cpopulation.pyx:834-835
+    const double* P = full + W.full_base + (int64_t)i * n * n;
+    double part = 0.0;
+    for (int k0 = 0; k0 < n; k0 += 256) {
+        const int nc = (n - k0 + 63) >> 6;
+        if (nc >= 4)      part += matvec_pass<4>(P, f, yv, n, k0, lane);
+        else if (nc == 3) part += matvec_pass<3>(P, f, yv, n, k0, lane);
+        else if (nc == 2) part += matvec_pass<2>(P, f, yv, n, k0, lane);
+        else              part += matvec_pass<1>(P, f, yv, n, k0, lane);
+    }
+    const double s = wave_sum(part);
+    if (MODE == 0) {
+        double* sh = S.share + S.share_base[w] + (int64_t)i * n;
+        for (int k = lane; k < n; k += 64) {
+            const double t = 2.0 * f[k] * yv[k];
+            sh[k] = s > 0.0 ? t / s : t;                                     // cpopulation.pyx:852-854
+        }
+        return;
+    }
+    double bv = 0.0;
+    int bj = 0x7fffffff;
+    for (int a = 0; a < n; ++a) {
+        const int64_t row = tri_row_start(a, n);
+        for (int b = a + lane; b < n; b += 64) {
+            double v = P[(int64_t)a * n + b] * f[a] * f[b] * (1 + (a != b));   // cpopulation.pyx:847
+            if (s > 0.0) v /= s;
+            const int j = (int)(row + b - a);
+            if (bj == 0x7fffffff || v > bv) { bv = v; bj = j; }             // cpopulation.pyx:791
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_xor(bv, off);
+        const int oj = __shfl_xor(bj, off);
+        if (oj != 0x7fffffff && (bj == 0x7fffffff || ov > bv || (ov == bv && oj < bj))) { bv = ov; bj = oj; }
+    }
+    if (lane == 0) { best_gen[W.ind_base + i] = bj; best_val[W.ind_base + i] = bv; }
+}
+
+__global__ __launch_bounds__(256) void k_em_step(const WinDesc* __restrict__ wins, const int32_t* __restrict__ ioff,
+                                                 const double* __restrict__ full, EmState S, int n_max)
+{
+    em_individual<0>(wins, ioff, full, S, n_max, nullptr, nullptr);
+}
+
+__global__ __launch_bounds__(256) void k_em_calls(const WinDesc* __restrict__ wins, const int32_t* __restrict__ ioff,
+                                                  const double* __restrict__ full, EmState S, int n_max,
+                                                  int32_t* __restrict__ best_gen, double* __restrict__ best_val)
+{
+    em_individual<1>(wins, ioff, full, S, n_max, best_gen, best_val);
+}
+
+__global__ __launch_bounds__(256) void k_em_update(const WinDesc* __restrict__ wins, const int32_t* __restrict__ ioff,
+                                                   EmState S, int max_iters)
+{
+    __shared__ double s_red[4];
+    const int w = blockIdx.x;
+    if (S.done[w]) return;
+    const WinDesc W = wins[w];
+    const int tid = threadIdx.x, n = W.n_hap;
+    const int32_t* io = ioff + W.ioff_base;
+    int n_with_data = 0;
+    for (int i = 0; i < W.n_ind; ++i) n_with_data += io[i + 1] != io[i];
+    const double* sh = S.share + S.share_base[w];
+    double ch = 0.0;
+    for (int k = tid; k < n; k += 256) {
+        double t = 0.0;
+        for (int i = 0; i < W.n_ind; ++i)
+            if (io[i + 1] != io[i]) t += sh[(int64_t)i * n + k];             // cpopulation.pyx:869-880, individual order
+        const double old = S.f[W.hap_base + k], nf = t / (2 * n_with_data);  // :883
+        S.f_prev[W.hap_base + k] = old;
+        S.f[W.hap_base + k] = nf;
+        ch = fmax(ch, fabs(old - nf));                                       // :885-888
+    }
+    ch = wave_max(ch);
+    if ((tid & 63) == 0) s_red[tid >> 6] = ch;
+    __syncthreads();
+    if (tid == 0) {
+        ch = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
+        double eps = 1.0 / (W.n_ind * 2 * 2);
+        eps = eps < 1e-3 ? eps : 1e-3;
+        const int it = S.iters[w] + 1;
+        S.iters[w] = it;
+        S.change[w] = ch;
+        if (!(ch > eps && it < max_iters)) {                                 // :766
+            S.done[w] = 1;
+            atomicSub(S.active, 1);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------

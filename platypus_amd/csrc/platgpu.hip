@@ -104,6 +104,10 @@ struct pg_ctx {
     DevBuf<double> d_cells, d_full, d_freq, d_em_change, d_best_val, d_var_prior, d_var_out;
     DevBuf<int64_t> d_var_moff;
     DevBuf<unsigned long long> d_win_max;
+    DevBuf<double> d_fprev, d_share;
+    DevBuf<int32_t> d_em_done;
+    DevBuf<int64_t> d_share_base;
+    int64_t win_share = 0;
     DevBuf<uint8_t> d_var_mask;
 
     // genotype scratch
@@ -215,7 +219,7 @@ int pg_ctx_destroy(pg_ctx* c) {
     c->d_vh.release(); c->d_anchor_in.release();
     c->d_n_flag.release(); c->d_wins.release(); c->d_ioff.release(); c->d_em_iters.release(); c->d_best_gen.release();
     c->d_var_win.release(); c->d_cells.release(); c->d_full.release(); c->d_freq.release(); c->d_em_change.release();
-    c->d_best_val.release(); c->d_var_prior.release(); c->d_var_out.release(); c->d_var_moff.release(); c->d_win_max.release(); c->d_rows.release(); c->d_var_mask.release(); c->d_vh_recs.release(); c->d_waves.release(); c->d_score.release(); c->d_anchor.release(); c->d_like.release();
+    c->d_best_val.release(); c->d_var_prior.release(); c->d_var_out.release(); c->d_var_moff.release(); c->d_win_max.release(); c->d_fprev.release(); c->d_share.release(); c->d_em_done.release(); c->d_share_base.release(); c->d_rows.release(); c->d_var_mask.release(); c->d_vh_recs.release(); c->d_waves.release(); c->d_score.release(); c->d_anchor.release(); c->d_like.release();
     c->d_g1.release(); c->d_g2.release(); c->d_gn.release(); c->d_gout.release();
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -646,7 +650,8 @@ int pg_windows_upload(pg_ctx* c, int nw, const int32_t* n_haps, const int32_t* n
         return fail(c, PG_ERR_INVALID, "pg_windows_upload: bad arguments");
     c->caller_done = false;
     std::vector<pg::WinDesc> wins((size_t)nw);
-    int64_t ioff = 0, cells = 0, full = 0, haps = 0, inds = 0;
+    int64_t ioff = 0, cells = 0, full = 0, haps = 0, inds = 0, share = 0;
+    std::vector<int64_t> share_base((size_t)nw + 1, 0);
     int max_h = 0, max_i = 0;
     int64_t max_full = 0;
     for (int w = 0; w < nw; ++w) {
@@ -667,6 +672,7 @@ int pg_windows_upload(pg_ctx* c, int nw, const int32_t* n_haps, const int32_t* n
         W.n_hap = nh; W.n_ind = ni; W.n_reads = nr; W.n_gen = nh * (nh + 1) / 2;
         W.like_base = like_base[w]; W.ioff_base = ioff; W.cell_base = cells; W.full_base = full;
         W.hap_base = haps; W.ind_base = inds;
+        share_base[w] = share; share += (int64_t)ni * nh;
         ioff += ni + 1; cells += (int64_t)ni * W.n_gen; full += (int64_t)ni * nh * nh; haps += nh; inds += ni;
         max_h = std::max(max_h, nh); max_i = std::max(max_i, ni);
         max_full = std::max(max_full, (int64_t)ni * nh * nh);
@@ -677,13 +683,16 @@ int pg_windows_upload(pg_ctx* c, int nw, const int32_t* n_haps, const int32_t* n
     PG_HIP(c, c->d_freq.reserve((size_t)haps + 1)); PG_HIP(c, c->d_em_iters.reserve((size_t)nw + 1));
     PG_HIP(c, c->d_em_change.reserve((size_t)nw + 1)); PG_HIP(c, c->d_best_gen.reserve((size_t)inds + 1));
     PG_HIP(c, c->d_best_val.reserve((size_t)inds + 1));
+    PG_HIP(c, c->d_share_base.reserve((size_t)nw + 1));
     if (nw > 0) {
+        PG_HIP(c, hipMemcpyAsync(c->d_share_base.p, share_base.data(), 8 * (size_t)nw, hipMemcpyHostToDevice, c->stream));
         PG_HIP(c, hipMemcpyAsync(c->d_wins.p, wins.data(), sizeof(pg::WinDesc) * nw, hipMemcpyHostToDevice, c->stream));
         PG_HIP(c, hipMemcpyAsync(c->d_ioff.p, ind_read_off, sizeof(int32_t) * ioff, hipMemcpyHostToDevice, c->stream));
         PG_HIP(c, hipStreamSynchronize(c->stream));
     }
     c->h_wins.swap(wins);
     c->n_windows = nw; c->max_win_haps = max_h; c->max_win_inds = max_i; c->max_win_full = max_full;
+    c->win_share = share;
     c->win_cells = cells; c->win_full = full; c->win_haps_total = haps; c->win_inds_total = inds;
     return PG_OK;
 }
@@ -718,15 +727,47 @@ int pg_caller_launch(pg_ctx* c, int max_iters) {
     if (c->max_win_full <= 4096) { stage = (int)c->max_win_full; lds += (size_t)stage * sizeof(double); }
     PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_em), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_CALLER_EM], c->stream));
-    const char* force = std::getenv("PG_EM_KERNEL");        // experiments: "big" forces the general kernel
-    if (n_max <= 8 && !(force && force[0] == 'b')) {
+    // Kernel choice: windows of at most 8 haplotypes take one wavefront each; few large windows with
+    // several individuals run one launch pair per iteration over (window, individuals) so that the
+    // whole chip works on them; everything else takes one workgroup per window.
+    // PG_EM_KERNEL = small | big | multi forces one of them (experiments, tests).
+    const char* force = std::getenv("PG_EM_KERNEL");
+    int path = n_max <= 8 ? 0 : (c->n_windows <= 256 && c->max_win_inds >= 4 ? 2 : 1);
+    if (force && force[0] == 'b') path = 1;
+    if (force && force[0] == 'm') path = 2;
+    if (force && force[0] == 's' && n_max <= 8) path = 0;
+    if (path == 0) {
         hipLaunchKernelGGL(pg::k_em_small, dim3((c->n_windows + 3) / 4), dim3(256), 0, c->stream,
                            c->d_wins.p, c->n_windows, c->d_ioff.p, c->d_full.p, max_iters,
                            c->d_freq.p, c->d_em_iters.p, c->d_em_change.p, c->d_best_gen.p, c->d_best_val.p);
-    } else {
+    } else if (path == 1) {
         hipLaunchKernelGGL(pg::k_em, dim3(c->n_windows), dim3(64 * n_wav), lds, c->stream,
                            c->d_wins.p, c->d_ioff.p, c->d_full.p, max_iters, n_max, stage,
                            c->d_freq.p, c->d_em_iters.p, c->d_em_change.p, c->d_best_gen.p, c->d_best_val.p);
+    } else {
+        PG_HIP(c, c->d_fprev.reserve((size_t)c->win_haps_total + 1));
+        PG_HIP(c, c->d_share.reserve((size_t)c->win_share + 1));
+        PG_HIP(c, c->d_em_done.reserve((size_t)c->n_windows + 1));     // [n_windows] = windows still running
+        pg::EmState S;
+        S.f = c->d_freq.p; S.f_prev = c->d_fprev.p; S.share = c->d_share.p; S.iters = c->d_em_iters.p;
+        S.change = c->d_em_change.p; S.done = c->d_em_done.p; S.active = c->d_em_done.p + c->n_windows;
+        S.share_base = c->d_share_base.p;
+        const dim3 grid2(c->n_windows, (c->max_win_inds + 3) / 4);
+        const size_t lds2 = (size_t)5 * n_max * sizeof(double);
+        PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_em_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_em_calls), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        hipLaunchKernelGGL(pg::k_em_init, dim3(c->n_windows), dim3(256), 0, c->stream, c->d_wins.p, c->n_windows, S);
+        int32_t active = c->n_windows;
+        for (int it = 0; it < max_iters && active > 0; ++it) {
+            hipLaunchKernelGGL(pg::k_em_step, grid2, dim3(256), lds2, c->stream, c->d_wins.p, c->d_ioff.p, c->d_full.p, S, n_max);
+            hipLaunchKernelGGL(pg::k_em_update, dim3(c->n_windows), dim3(256), 0, c->stream, c->d_wins.p, c->d_ioff.p, S, max_iters);
+            if ((it & 7) == 7) {                            // every eight iterations: anything left to do?
+                PG_HIP(c, hipMemcpyAsync(&active, S.active, sizeof active, hipMemcpyDeviceToHost, c->stream));
+                PG_HIP(c, hipStreamSynchronize(c->stream));
+            }
+        }
+        hipLaunchKernelGGL(pg::k_em_calls, grid2, dim3(256), lds2, c->stream, c->d_wins.p, c->d_ioff.p, c->d_full.p, S, n_max,
+                           c->d_best_gen.p, c->d_best_val.p);
     }
     PG_HIP(c, hipGetLastError());
     PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_CALLER_EM + 1], c->stream));

@@ -142,3 +142,40 @@ def test_small_window_kernel_equals_general_kernel(monkeypatch):
             ctx.close()
     for k in ("freq", "iters", "max_change", "best_gen", "best_val", "post"):
         assert np.array_equal(out["small"][k], out["big"][k]), k
+
+
+@pytest.mark.parametrize("which", ["big", "multi"])
+def test_em_kernel_paths_against_checker(monkeypatch, which):
+    """the one-workgroup-per-window kernel and the launch-pair-per-iteration path, each forced"""
+    monkeypatch.setenv("PG_EM_KERNEL", which)
+    run_case(n_windows=5, H=40, R=120, n_ind=9, seed=41, indel_frac=0.2, empty=2)
+    run_case(n_windows=7, H=5, R=40, n_ind=3, seed=42)
+    monkeypatch.setenv("PG_EM_KERNEL", which)
+
+
+def test_em_iteration_cap(monkeypatch):
+    """max_iters is honoured by every path (the reference's default is 100, cpopulation.pyx:741)"""
+    from platypus_amd import native
+    from oracle import pyoracle as po
+    H, R, n_ind, nw = 12, 60, 5, 4
+    b = synth.make_batch(n_windows=nw, haps_per_window=H, reads_per_window=R, read_len=50, hap_len=260, seed=43)
+    off = np.linspace(0, R, n_ind + 1).astype(np.int32)
+    for which in ("big", "multi"):
+        monkeypatch.setenv("PG_EM_KERNEL", which)
+        ctx = native.AlignContext(0)
+        try:
+            ctx.upload_batch(b)
+            ctx.launch()
+            ctx.upload_windows([H] * nw, [n_ind] * nw, np.arange(nw, dtype=np.int64) * H * R, np.tile(off, nw))
+            _, _, like = ctx.fetch()
+            for cap in (0, 1, 3, 9):
+                ctx.caller_launch(cap)
+                res = ctx.caller_fetch()
+                for w in range(nw):
+                    post = po.caller_setup(like[w * H * R:(w + 1) * H * R].reshape(H, R), off)
+                    ref = po.caller_call(post, off, H, max_iters=cap)
+                    assert res["iters"][w] == ref["iters"] <= cap
+                    np.testing.assert_allclose(res["freq"][w * H:(w + 1) * H], ref["freq"], rtol=RTOL, atol=1e-300)
+                    np.testing.assert_allclose(res["best_val"][w * n_ind:(w + 1) * n_ind], ref["best_val"], rtol=RTOL, atol=1e-300)
+        finally:
+            ctx.close()
