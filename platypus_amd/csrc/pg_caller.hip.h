@@ -9,6 +9,7 @@
 // platypus/cgenotype.pyx:90-96; packed index of (a, b): a n - a (a - 1) / 2 + b - a.
 //
 //   k_gl          log-likelihood of every (individual, genotype), maximum per window
+//   k_gl_tile     the same for windows with many haplotypes, likelihood columns staged in LDS
 //   k_norm        exp(ll - maximum of the window); also written as full symmetric
 //                 n x n matrices, the layout the EM streams
 //   k_em          EM iterations and genotype calls, one workgroup per window
@@ -140,6 +141,72 @@ __global__ __launch_bounds__(256) void k_gl(const WinDesc* __restrict__ wins, in
     } else if (nr > 0) {
         atomicMax(&win_max[w], ordered_bits(s));
     }
+}
+
+// ---------------------------------------------------------------------------
+// k_gl_tile: the same sums for windows with many haplotypes.  One workgroup per
+// (window, individual): the individual's likelihood columns L[h][r] are staged
+// in LDS in chunks of reads (row stride odd, so the lanes of a wavefront, which
+// hold consecutive second haplotypes b, fall into different banks), and every
+// thread walks the genotypes g = tid, tid + 256, ... keeping (a, b) by
+// increments.  Reads are added in read order, chunk after chunk (partial sums
+// rest in ll between chunks).  k_gl reads L straight from global memory, with
+// every lane of a wavefront on a different cache line; here the reads of L are
+// coalesced once and the 2 x n_gen x n_reads operand fetches hit LDS.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gl_tile(const WinDesc* __restrict__ wins, int n_win,
+                                                 const int32_t* __restrict__ ioff,
+                                                 const double* __restrict__ like,
+                                                 double* __restrict__ ll, unsigned long long* __restrict__ win_max,
+                                                 int lds_doubles)
+{
+    extern __shared__ double gl_lds[];
+    __shared__ double s_red[4];
+    const int tid = threadIdx.x;
+    int lo = 0, hi = n_win - 1;                      // last window with ind_base <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (wins[mid].ind_base <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const int w = lo;
+    const WinDesc W = wins[w];
+    const int i = (int)(blockIdx.x - W.ind_base), n = W.n_hap;
+    const int r0 = ioff[W.ioff_base + i], nr = ioff[W.ioff_base + i + 1] - r0;
+    double* out = ll + W.cell_base + (int64_t)i * W.n_gen;
+    if (nr == 0) {                                   // cpopulation.pyx:717-718
+        for (int g = tid; g < W.n_gen; g += 256) out[g] = 0.0;
+        return;
+    }
+    int chunk = lds_doubles / n;                     // reads per chunk
+    chunk = chunk > nr ? nr : chunk;
+    if (!(chunk & 1) && chunk > 1) --chunk;          // odd row stride
+    const int stride = chunk | 1;
+    const double* L = like + W.like_base + r0;
+    double mx = -1e7;
+    for (int rc = 0; rc < nr; rc += chunk) {
+        const int cn = nr - rc < chunk ? nr - rc : chunk;
+        __syncthreads();
+        for (int k = tid; k < n * cn; k += 256) {
+            const int h = k / cn, r = k - h * cn;
+            gl_lds[h * stride + r] = L[(int64_t)h * W.n_reads + rc + r];
+        }
+        __syncthreads();
+        int a = 0, p = tid;                          // genotype (a, a + p)
+        for (int g = tid; g < W.n_gen; g += 256) {
+            while (p >= n - a) { p -= n - a; ++a; }
+            const double* l1 = gl_lds + a * stride;
+            const double* l2 = gl_lds + (a + p) * stride;
+            double s = rc == 0 ? 0.0 : out[g];
+            for (int r = 0; r < cn; ++r) s += log(0.5 * (l1[r] + l2[r]));       // cgenotype.pyx:58-61
+            out[g] = s;
+            if (rc + cn >= nr) mx = fmax(mx, s);
+            p += 256;
+        }
+    }
+    mx = wave_max(mx);
+    if ((tid & 63) == 0) s_red[tid >> 6] = mx;
+    __syncthreads();
+    if (tid == 0) atomicMax(&win_max[w], ordered_bits(fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]))));
 }
 
 // ---------------------------------------------------------------------------

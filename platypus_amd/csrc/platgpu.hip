@@ -709,8 +709,18 @@ int pg_caller_launch(pg_ctx* c, int max_iters) {
     PG_HIP(c, c->d_win_max.reserve((size_t)c->n_windows));
     hipLaunchKernelGGL(pg::k_fill_u64, dim3((c->n_windows + 255) / 256), dim3(256), 0, c->stream,
                        c->d_win_max.p, c->n_windows, -1e7);
-    hipLaunchKernelGGL(pg::k_gl, dim3((unsigned)((c->win_cells + 255) / 256)), dim3(256), 0, c->stream,
-                       c->d_wins.p, c->n_windows, c->d_ioff.p, c->d_like.p, c->d_cells.p, c->d_win_max.p, c->win_cells);
+    const char* glk = std::getenv("PG_GL_KERNEL");           // experiments / tests: "cell" or "tile"
+    const bool tile = glk ? glk[0] == 't' : c->max_win_haps >= 24;   // >= 300 genotypes: a workgroup has work
+    if (tile) {
+        const int lds_doubles = std::max(6 * 1024, c->max_win_haps);  // 48 KiB, at least one read per chunk
+        PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_gl_tile), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)(lds_doubles * sizeof(double))));
+        hipLaunchKernelGGL(pg::k_gl_tile, dim3((unsigned)c->win_inds_total), dim3(256), lds_doubles * sizeof(double), c->stream,
+                           c->d_wins.p, c->n_windows, c->d_ioff.p, c->d_like.p, c->d_cells.p, c->d_win_max.p, lds_doubles);
+    } else {
+        hipLaunchKernelGGL(pg::k_gl, dim3((unsigned)((c->win_cells + 255) / 256)), dim3(256), 0, c->stream,
+                           c->d_wins.p, c->n_windows, c->d_ioff.p, c->d_like.p, c->d_cells.p, c->d_win_max.p, c->win_cells);
+    }
     PG_HIP(c, hipGetLastError());
     hipLaunchKernelGGL(pg::k_norm, dim3((unsigned)((c->win_cells + 255) / 256)), dim3(256), 0, c->stream,
                        c->d_wins.p, c->n_windows, c->d_win_max.p, c->d_cells.p, c->d_full.p, c->win_cells);

@@ -179,3 +179,12 @@ def test_em_iteration_cap(monkeypatch):
                     np.testing.assert_allclose(res["best_val"][w * n_ind:(w + 1) * n_ind], ref["best_val"], rtol=RTOL, atol=1e-300)
         finally:
             ctx.close()
+
+
+@pytest.mark.parametrize("which", ["cell", "tile"])
+def test_genotype_likelihood_kernels(monkeypatch, which):
+    """one thread per cell from global memory, and the LDS-tiled kernel (incl. several read chunks per individual)"""
+    monkeypatch.setenv("PG_GL_KERNEL", which)
+    run_case(n_windows=2, H=257, R=60, n_ind=2, seed=51, indel_frac=0.1, read_len=40, hap_len=200)
+    run_case(n_windows=9, H=4, R=33, n_ind=3, seed=52, empty=0)
+    run_case(n_windows=3, H=30, R=90, n_ind=4, seed=53, indel_frac=0.2)
