@@ -143,6 +143,26 @@ int pg_align_pairs(pg_ctx *ctx, int64_t n_pairs, const int32_t *hap_idx, const i
                    int32_t *score, int32_t *anchor, double *likelihood);
 
 /*
+ * hash_sequence of the reference on its own (platypus/calign.pyx:99-123): the
+ * table of unique 7-mer starts of `seq` in the reference's layout -- int32[16384],
+ * index my_hash (platypus/calign.pyx:81-96), value i+1, -1 for a 7-mer seen more
+ * than once, 0 for an absent one; the last 7-mer is left out as in the reference.
+ * len must be below 16384 (platypus/calign.pyx:112); a sequence shorter than 7
+ * gives the empty table.  The alignment path does not need this call (its
+ * table lives in LDS); it exists for callers of the reference's cdef function.
+ */
+int pg_hash_sequence(pg_ctx *ctx, const char *seq, int len, int32_t *table);
+
+/*
+ * map_read of the reference on its own (platypus/calign.pyx:126-158): the start
+ * of `read` in a sequence of length seq_len whose table (as made by
+ * pg_hash_sequence) is given; may be negative; 0 if nothing votes or the read
+ * is shorter than 7.  A table entry that points outside the sequence (the
+ * reference's assertion, platypus/calign.pyx:148) is an error.
+ */
+int pg_map_read(pg_ctx *ctx, const char *read, int read_len, int seq_len, const int32_t *table, int32_t *position);
+
+/*
  * Device time in milliseconds of kernel group `which` in the last
  * pg_align_launch / pg_genotype_loglik / pg_caller_launch, measured with HIP events on the
  * context's stream.  Synchronises.

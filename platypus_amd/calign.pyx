@@ -4,9 +4,10 @@
 ``alignNoTraceback`` keeps the signature of platypus/calign.pyx:36 but sends the
 pair to the HIP kernels of libplatgpu.so; ``alignBatch`` is the form the rest of
 this package uses: every haplotype of a window against every read of an
-individual in one launch.  hash_sequence / map_read of the reference
-(platypus/calign.pyx:99-158) have no host counterpart here: the 7-mer table
-lives in LDS inside the device's anchoring kernel.  There is no CPU fallback.
+individual in one launch.  The alignment path keeps its 7-mer table in LDS inside
+the device's anchoring kernel; ``hash_sequence`` / ``map_read`` (platypus/calign.pyx:99-158)
+exist for callers of those cdef functions and run on the device as well.  There is
+no CPU fallback.
 """
 import os
 
@@ -119,6 +120,41 @@ cdef double alignNoTraceback(cAlignedRead* read, char* hapSeq, int hapStart, int
     alignBatch(1, &hapSeq, &hapStart, &varSeqLen, &hapLen, &one, &one + 1,
                homopolgapq_or_localgapopen, gapextend, nucprior, &like, NULL, NULL)
     return like
+
+
+cdef int* hash_sequence(char* sequence) except NULL:
+    """platypus/calign.pyx:99-123; the caller frees the table."""
+    cdef pg_ctx* ctx = deviceContext()
+    cdef int* h = <int*>malloc(16384 * sizeof(int))
+    cdef int rc = pg_hash_sequence(ctx, sequence, <int>strlen(sequence), <int32_t*>h)
+    if rc != PG_OK:
+        free(h)
+        check(rc)
+    return h
+
+
+cdef int map_read(char* read, int sequence_length, int* sequence_hash) except? -2147483647:
+    """platypus/calign.pyx:126-158"""
+    cdef pg_ctx* ctx = deviceContext()
+    cdef int32_t pos = 0
+    check(pg_map_read(ctx, read, <int>strlen(read), sequence_length, <int32_t*>sequence_hash, &pos))
+    return pos
+
+
+def hashSequencePy(bytes sequence):
+    cdef int* h = hash_sequence(sequence)
+    try:
+        return [h[i] for i in range(16384)]
+    finally:
+        free(h)
+
+
+def mapReadPy(bytes read, bytes sequence):
+    cdef int* h = hash_sequence(sequence)
+    try:
+        return map_read(read, <int>len(sequence), h)
+    finally:
+        free(h)
 
 
 def closeDevice():

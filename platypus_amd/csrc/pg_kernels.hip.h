@@ -394,6 +394,56 @@ __global__ __launch_bounds__(256) void k_vote4(const uint32_t* __restrict__ hap2
 }
 
 // ---------------------------------------------------------------------------
+// Stand-alone forms of hash_sequence and map_read (platypus/calign.pyx:99-158)
+// for callers that use them outside alignNoTraceback: the table in the
+// reference's own layout (int32[16384], index = my_hash with the first base in
+// the high bits, value i+1 / -1 / 0) and one read mapped against such a table.
+// Compatibility paths, one small launch each; the alignment path itself uses
+// k_vote4.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t my_hash_bytes(const uint8_t* p) {       // calign.pyx:81-96
+    uint32_t h = 0;
+#pragma unroll
+    for (int i = 0; i < kHashNucs; ++i) h = (h << 2) + nuc_code(p[i]);
+    return h;
+}
+
+__global__ __launch_bounds__(1024) void k_hash_sequence(const uint8_t* __restrict__ seq, int len, int32_t* __restrict__ table)
+{
+    const int tid = threadIdx.x;
+    for (int i = tid; i < kHashSize; i += 1024) table[i] = 0;               // calloc, calign.pyx:105
+    __syncthreads();
+    const int nk = len - kHashNucs;                                          // calign.pyx:114
+    for (int i = tid; i < nk; i += 1024) table[my_hash_bytes(seq + i)] = i + 1;
+    __syncthreads();
+    for (int i = tid; i < nk; i += 1024) {
+        const uint32_t k = my_hash_bytes(seq + i);
+        if (table[k] != i + 1) table[k] = -1;                                // seen more than once, calign.pyx:118-119
+    }
+}
+
+// The reference's loop as it stands (calign.pyx:143-155), one thread: the vote order decides ties.
+__global__ void k_map_read(const uint8_t* __restrict__ read, int rlen, int seq_len,
+                           const int32_t* __restrict__ table, int32_t* __restrict__ counts,
+                           int32_t* __restrict__ out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int maxcount = 0, maxpos = 0, bad = 0;
+    for (int i = 0; i < rlen - kHashNucs; ++i) {
+        int pos = table[my_hash_bytes(read + i)];
+        if (pos > 0) {
+            pos -= 1 + i;
+            if (pos >= seq_len || pos + rlen < 0) { bad = 1; continue; }     // assertion at calign.pyx:148
+            const int count = counts[pos + rlen] + 1;
+            counts[pos + rlen] = count;
+            if (count > maxcount) { maxcount = count; maxpos = pos; }
+        }
+    }
+    out[0] = maxpos;
+    out[1] = bad;
+}
+
+// ---------------------------------------------------------------------------
 // k_genotype: out[g] = sum_r log(0.5*(L[b1+r] + L[b2+r])), read order
 // (platypus/cgenotype.pyx:58-61).  One wavefront per genotype row: lanes take
 // reads r = lane, lane+64, ...; partial sums are combined in a fixed tree, so

@@ -114,6 +114,8 @@ struct pg_ctx {
     DevBuf<int64_t> d_g1, d_g2;
     DevBuf<int32_t> d_gn;
     DevBuf<double> d_gout, d_rows;
+    DevBuf<uint8_t> d_cmp_bytes;         // stand-alone hash_sequence / map_read
+    DevBuf<int32_t> d_cmp_ints;
 };
 
 namespace {
@@ -219,7 +221,7 @@ int pg_ctx_destroy(pg_ctx* c) {
     c->d_vh.release(); c->d_anchor_in.release();
     c->d_n_flag.release(); c->d_wins.release(); c->d_ioff.release(); c->d_em_iters.release(); c->d_best_gen.release();
     c->d_var_win.release(); c->d_cells.release(); c->d_full.release(); c->d_freq.release(); c->d_em_change.release();
-    c->d_best_val.release(); c->d_var_prior.release(); c->d_var_out.release(); c->d_var_moff.release(); c->d_win_max.release(); c->d_fprev.release(); c->d_share.release(); c->d_em_done.release(); c->d_share_base.release(); c->d_rows.release(); c->d_var_mask.release(); c->d_vh_recs.release(); c->d_waves.release(); c->d_score.release(); c->d_anchor.release(); c->d_like.release();
+    c->d_best_val.release(); c->d_var_prior.release(); c->d_var_out.release(); c->d_var_moff.release(); c->d_win_max.release(); c->d_fprev.release(); c->d_share.release(); c->d_em_done.release(); c->d_share_base.release(); c->d_rows.release(); c->d_cmp_bytes.release(); c->d_cmp_ints.release(); c->d_var_mask.release(); c->d_vh_recs.release(); c->d_waves.release(); c->d_score.release(); c->d_anchor.release(); c->d_like.release();
     c->d_g1.release(); c->d_g2.release(); c->d_gn.release(); c->d_gout.release();
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -615,6 +617,49 @@ int pg_genotype_loglik(pg_ctx* c, int64_t ng, const int64_t* b1, const int64_t* 
     c->ev_valid[PG_K_GENOTYPE] = true;
     PG_HIP(c, hipMemcpyAsync(out, c->d_gout.p, ng * 8, hipMemcpyDeviceToHost, c->stream));
     PG_HIP(c, hipStreamSynchronize(c->stream));
+    return PG_OK;
+}
+
+int pg_hash_sequence(pg_ctx* c, const char* seq, int len, int32_t* table) {
+    if (!c) return PG_ERR_INVALID;
+    if (!seq || !table || len < 0) return fail(c, PG_ERR_INVALID, "pg_hash_sequence: bad arguments");
+    if (len >= pg::kHashSize) return fail(c, PG_ERR_UNSUPPORTED, "sequence of %d bases (limit 16383, calign.pyx:112)", len);
+    PG_HIP(c, hipSetDevice(c->device));
+    PG_HIP(c, c->d_cmp_bytes.reserve((size_t)len + 16));
+    PG_HIP(c, c->d_cmp_ints.reserve(pg::kHashSize));
+    if (len > 0) PG_HIP(c, hipMemcpyAsync(c->d_cmp_bytes.p, seq, len, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(pg::k_hash_sequence, dim3(1), dim3(1024), 0, c->stream, c->d_cmp_bytes.p,
+                       len < pg::kHashNucs ? 0 : len, c->d_cmp_ints.p);
+    PG_HIP(c, hipGetLastError());
+    PG_HIP(c, hipMemcpyAsync(table, c->d_cmp_ints.p, pg::kHashSize * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    PG_HIP(c, hipStreamSynchronize(c->stream));
+    return PG_OK;
+}
+
+int pg_map_read(pg_ctx* c, const char* read, int rlen, int seq_len, const int32_t* table, int32_t* position) {
+    if (!c) return PG_ERR_INVALID;
+    if (!read || !table || !position || rlen < 0 || seq_len < 0)
+        return fail(c, PG_ERR_INVALID, "pg_map_read: bad arguments");
+    if (seq_len >= pg::kHashSize) return fail(c, PG_ERR_UNSUPPORTED, "sequence of %d bases (limit 16383, calign.pyx:132)", seq_len);
+    *position = 0;
+    if (rlen < pg::kHashNucs) return PG_OK;                       // calign.pyx:140-141
+    PG_HIP(c, hipSetDevice(c->device));
+    const size_t n_counts = (size_t)seq_len + rlen;
+    PG_HIP(c, c->d_cmp_bytes.reserve((size_t)rlen + 16));
+    PG_HIP(c, c->d_cmp_ints.reserve(pg::kHashSize + n_counts + 2));
+    int32_t* d_table = c->d_cmp_ints.p;
+    int32_t* d_counts = d_table + pg::kHashSize;
+    int32_t* d_out = d_counts + n_counts;
+    PG_HIP(c, hipMemcpyAsync(c->d_cmp_bytes.p, read, rlen, hipMemcpyHostToDevice, c->stream));
+    PG_HIP(c, hipMemcpyAsync(d_table, table, pg::kHashSize * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    PG_HIP(c, hipMemsetAsync(d_counts, 0, (n_counts + 2) * sizeof(int32_t), c->stream));
+    hipLaunchKernelGGL(pg::k_map_read, dim3(1), dim3(64), 0, c->stream, c->d_cmp_bytes.p, rlen, seq_len, d_table, d_counts, d_out);
+    PG_HIP(c, hipGetLastError());
+    int32_t out[2] = {0, 0};
+    PG_HIP(c, hipMemcpyAsync(out, d_out, sizeof out, hipMemcpyDeviceToHost, c->stream));
+    PG_HIP(c, hipStreamSynchronize(c->stream));
+    if (out[1]) return fail(c, PG_ERR_INVALID, "the table points outside the sequence (assertion of calign.pyx:148)");
+    *position = out[0];
     return PG_OK;
 }
 

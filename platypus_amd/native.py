@@ -37,6 +37,8 @@ SYMBOLS = {
     "pg_align_pairs": (C.c_int, [C.c_void_p, C.c_int64, _i32p, _i32p, _i32p, _i32p, _f64p]),
     "pg_kernel_time_ms": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
     "pg_genotype_loglik": (C.c_int, [C.c_void_p, C.c_int64, _i64p, _i64p, _i32p, _f64p]),
+    "pg_hash_sequence": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, _i32p]),
+    "pg_map_read": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, _i32p, C.POINTER(C.c_int32)]),
     "pg_genotype_loglik_rows": (C.c_int, [C.c_void_p, C.c_int, _f64p, _f64p, C.POINTER(C.c_double)]),
     "pg_windows_upload": (C.c_int, [C.c_void_p, C.c_int, _i32p, _i32p, _i64p, _i32p]),
     "pg_caller_launch": (C.c_int, [C.c_void_p, C.c_int]),
@@ -178,6 +180,17 @@ class AlignContext(object):
         out = np.empty(len(b1), dtype=np.float64)
         self._check(LIB.pg_genotype_loglik(self._h, len(b1), _ptr(b1), _ptr(b2), _ptr(nr), _ptr(out)))
         return out
+
+    def hash_sequence(self, seq):
+        table = np.empty(16384, dtype=np.int32)
+        self._check(LIB.pg_hash_sequence(self._h, bytes(seq), len(seq), _ptr(table)))
+        return table
+
+    def map_read(self, read, seq_len, table):
+        t = _arr(table, np.int32)
+        pos = C.c_int32(0)
+        self._check(LIB.pg_map_read(self._h, bytes(read), len(read), seq_len, _ptr(t), C.byref(pos)))
+        return pos.value
 
     def genotype_loglik_rows(self, row1, row2):
         r1 = _arr(row1, np.float64); r2 = _arr(row2, np.float64)

@@ -32,3 +32,5 @@ cdef extern from "platgpu.h":
     int pg_genotype_loglik_rows(pg_ctx* ctx, int n_reads, const double* row1, const double* row2, double* out)
     int pg_pairs_blocks(pg_ctx* ctx, int n_blocks, const int32_t* hap_lo, const int32_t* n_haps,
                         const int32_t* read_lo, const int32_t* n_reads, int64_t* pair_base)
+    int pg_hash_sequence(pg_ctx* ctx, const char* seq, int len, int32_t* table)
+    int pg_map_read(pg_ctx* ctx, const char* read, int read_len, int seq_len, const int32_t* table, int32_t* position)

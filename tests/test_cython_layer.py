@@ -328,3 +328,19 @@ def test_site_likelihoods_second_alignment_site():
     # the genotype/EM results of run() are still reachable
     assert 0.0 <= pops[0].calculatePosteriorPy(items[0][2].variantsPy()[0]) <= 1.0
     calign.closeDevice()
+
+
+@pytest.mark.gpu
+def test_hash_sequence_and_map_read_cdefs():
+    """the reference's cdef hash_sequence / map_read (calign.pxd:5, calign.pyx:99-158) through the Cython layer"""
+    from oracle import pyoracle as po
+    from platypus_amd import calign
+    rng = np.random.default_rng(8)
+    seq = bytes(b"ACGT"[i] for i in rng.integers(0, 4, 800))
+    want = po.hash_sequence(seq)
+    assert calign.hashSequencePy(seq) == list(want)
+    for o in (0, 13, 400, 700):
+        read = seq[o:o + 90]
+        assert calign.mapReadPy(read, seq) == po.map_read(read, len(seq), want) == o
+    assert calign.mapReadPy(b"ACG", seq) == 0
+    calign.closeDevice()

@@ -186,3 +186,40 @@ def test_genotype_loglik(ctx):
     got = ctx.genotype_loglik(b1, b2, np.full(len(b1), R, np.int32))
     exp = np.array([po.genotype_loglik(like[x:x + R], like[y:y + R]) for x, y in zip(b1, b2)])
     assert np.all(np.abs(got - exp) <= 1e-9 * np.abs(exp) + 1e-300)   # 1e-9 relative
+
+
+def test_standalone_hash_sequence_and_map_read():
+    """pg_hash_sequence / pg_map_read against the restatement of calign.pyx:99-158, bit for bit"""
+    from platypus_amd import native
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(123)
+    ctx = native.AlignContext(0)
+    try:
+        for case in range(12):
+            n = [0, 5, 7, 8, 60, 300, 900, 2500, 16383, 700, 700, 700][case]
+            seq = bytes(b"ACGTN"[i] for i in rng.choice(5, size=n, p=[0.245, 0.245, 0.245, 0.245, 0.02]))
+            if case == 9:
+                seq = (b"ACGTTGCA" * 100)[:700]                     # every 7-mer repeated
+            tab = ctx.hash_sequence(seq)
+            want = np.asarray(po.hash_sequence(seq), dtype=np.int32)
+            assert np.array_equal(tab, want), case
+            for _ in range(6):
+                rl = int(rng.integers(1, 200))
+                if n > rl + 20 and rng.random() < 0.8:
+                    o = int(rng.integers(0, n - rl))
+                    read = bytearray(seq[o:o + rl])
+                    for j in np.flatnonzero(rng.random(rl) < 0.03):
+                        read[j] = b"ACGT"[int(rng.integers(0, 4))]
+                    if rl > 40 and rng.random() < 0.5:
+                        del read[20:23]
+                    read = bytes(read)
+                else:
+                    read = bytes(b"ACGT"[i] for i in rng.integers(0, 4, rl))
+                assert ctx.map_read(read, n, tab) == po.map_read(read, n, want), (case, rl)
+        with pytest.raises(native.PlatGpuError):
+            ctx.hash_sequence(b"A" * 16384)
+        bad = np.zeros(16384, dtype=np.int32); bad[:] = 5000
+        with pytest.raises(native.PlatGpuError):
+            ctx.map_read(b"ACGTACGTACGT", 100, bad)
+    finally:
+        ctx.close()
