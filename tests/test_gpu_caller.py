@@ -96,6 +96,12 @@ def test_wide_windows_all_column_chunk_shapes(H):
     run_case(n_windows=2, H=H, R=36, n_ind=3, seed=30 + H, indel_frac=0.1, read_len=40, hap_len=200)
 
 
+def test_very_wide_window():
+    """600 haplotypes (180 300 genotypes): several 256-column passes, large LDS rows, both EM paths"""
+    run_case(n_windows=1, H=600, R=20, n_ind=2, seed=61, indel_frac=0.05, read_len=30, hap_len=120)
+    run_case(n_windows=1, H=600, R=24, n_ind=5, seed=62, indel_frac=0.05, read_len=30, hap_len=120)
+
+
 def test_two_haplotypes():
     run_case(n_windows=40, H=2, R=16, n_ind=2, seed=14)
 

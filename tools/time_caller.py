@@ -22,6 +22,8 @@ def main():
     max_iters = int(sys.argv[3]) if len(sys.argv) > 3 else 100
     H, R, extra, _ = bench.WORKLOADS[wl]
     n_ind = 50 if wl == "joint" else 1
+    # shape overrides for experiments: TC_H, TC_R, TC_IND
+    H = int(os.environ.get("TC_H", H)); R = int(os.environ.get("TC_R", R)); n_ind = int(os.environ.get("TC_IND", n_ind))
     nw = max(1, windows * 128 // (H * R))
     b = synth.make_batch(n_windows=nw, haps_per_window=H, reads_per_window=R, read_len=150, hap_len=750,
                          seed=synth.SEED, **extra)
