@@ -280,6 +280,10 @@ cdef class WindowBatch:
         self.windows.append((haplotypes, readBuffers, counts, ptrs))
         return len(self.windows) - 1
 
+    def readCounts(self, int w):
+        """reads per individual of window w"""
+        return list(self.windows[w][2])
+
     def run(self, int maxIters=100):
         cdef pg_ctx* ctx = deviceContext()
         cdef int nW = len(self.windows), w, h, i, r, n

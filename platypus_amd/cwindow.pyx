@@ -29,6 +29,44 @@ cdef int bisectReadsLeft(cAlignedRead** reads, int testPos, int nReads):
     return low
 
 
+cdef int checkAndTrimRead(cAlignedRead* theRead, cAlignedRead* theLastRead, int maxBadQualBases,
+                          int minGoodQualBases):
+    """platypus/cwindow.pyx:74-146: 0 = drop the record; otherwise its low-quality ends (and, for a
+    fragment shorter than two reads, the forward read's overlap with its mate) get quality 0."""
+    cdef int index
+    if theRead.rlen - theRead.nQualsBelow20 < minGoodQualBases:
+        return 0
+    if theRead.nQualsBelow20 > maxBadQualBases:
+        return 0
+    if theRead.isUnMapped or theRead.isDuplicate:
+        return 0
+    if theRead.insertSize > 0 and (not theRead.isReverse) and theRead.mateIsReverse and theRead.insertSize < theRead.rlen:
+        return 0
+    if theRead.insertSize < 0 and theRead.isReverse and (not theRead.mateIsReverse) and -1 * theRead.insertSize < theRead.rlen:
+        return 0
+    if theLastRead != NULL:
+        if theRead.pos == theLastRead.pos and theRead.rlen == theLastRead.rlen:
+            if theRead.isPaired:
+                if theLastRead.matePos == theRead.matePos:
+                    return 0
+            else:
+                return 0
+    for index in range(1, theRead.rlen + 1):
+        if theRead.qual[theRead.rlen - index] < 5:
+            theRead.qual[theRead.rlen - index] = 0
+        else:
+            break
+    for index in range(theRead.rlen):
+        if theRead.qual[index] < 5:
+            theRead.qual[index] = 0
+        else:
+            break
+    if theRead.insertSize > 0 and (not theRead.isReverse) and theRead.mateIsReverse and theRead.insertSize < 2 * theRead.rlen:
+        for index in range(1, (2 * theRead.rlen - theRead.insertSize) + 1):
+            theRead.qual[theRead.rlen - index] = 0
+    return 1
+
+
 cdef class bamReadBuffer:
     def __init__(self, bytes chrom, int start, int end, seq, qual, off, pos, readEnd, mapq):
         """Reads must be sorted by pos (the BAM order the reference relies on)."""
@@ -68,14 +106,112 @@ cdef class bamReadBuffer:
         self.windowStart = self.cReads
         self.windowEnd = self.cReads + n
 
+    @staticmethod
+    def fromAlignments(bytes chrom, int start, int end, seq, qual, off, pos, mapq, flag, cigar, cigarOff,
+                       insertSize=None, matePos=None, int minMapQual=20, int maxReads=5000000,
+                       int minGoodQualBases=20, int maxBadQualBases=20):
+        """The buffer the reference builds from a BAM region (cwindow.pyx:156-229), from the same
+        per-record fields in packed arrays: bases, raw qualities and their offsets, pos, mapq,
+        the BAM flag word, CIGAR words (length << 4 | op, the BAM encoding) with per-read offsets,
+        insert size and mate position.  Applies the reference's record handling in its order:
+        mapping-quality cut (cwindow.pyx:188-190), the derived fields of createRead
+        (samtoolsWrapper.pyx:699-789), checkAndTrimRead (cwindow.pyx:74-146: quality counts,
+        unmapped / duplicate / short-insert / repeated-position records dropped, low-quality heads
+        and tails and the overlap of short fragments set to quality 0), the read limit."""
+        cdef const unsigned char[::1] s = np.ascontiguousarray(seq, dtype=np.uint8)
+        cdef const unsigned char[::1] q = np.ascontiguousarray(qual, dtype=np.uint8)
+        cdef const long long[::1] o = np.ascontiguousarray(off, dtype=np.int64)
+        cdef const int[::1] p = np.ascontiguousarray(pos, dtype=np.int32)
+        cdef const int[::1] m = np.ascontiguousarray(mapq, dtype=np.int32)
+        cdef const int[::1] fl = np.ascontiguousarray(flag, dtype=np.int32)
+        cdef const unsigned int[::1] cg = np.ascontiguousarray(cigar, dtype=np.uint32)
+        cdef const long long[::1] co = np.ascontiguousarray(cigarOff, dtype=np.int64)
+        cdef int n = <int>(o.shape[0] - 1)
+        cdef const int[::1] isz = np.ascontiguousarray(insertSize if insertSize is not None else np.zeros(n), dtype=np.int32)
+        cdef const int[::1] mp = np.ascontiguousarray(matePos if matePos is not None else np.full(n, -1), dtype=np.int32)
+        cdef bamReadBuffer self = bamReadBuffer.__new__(bamReadBuffer)
+        cdef int i, k, rl, nc, count = 0, index
+        cdef cAlignedRead* r
+        cdef cAlignedRead* last
+        self.chromBytes = chrom
+        self.chrom = self.chromBytes
+        self.startBase = start
+        self.endBase = end
+        self.longestRead = 0
+        self.nReads = 0
+        self.cReads = <cAlignedRead**>malloc((n + 1) * sizeof(cAlignedRead*))
+        for i in range(n):
+            if m[i] < minMapQual:                                   # cwindow.pyx:188-190
+                continue
+            rl = <int>(o[i + 1] - o[i])
+            if rl == 0 or q[o[i]] == 0xff:                          # samtoolsWrapper.pyx:712-719
+                continue
+            r = <cAlignedRead*>calloc(1, sizeof(cAlignedRead))
+            r.seq = <char*>calloc(rl + 1, 1)
+            r.qual = <char*>calloc(rl + 1, 1)
+            memcpy(r.seq, &s[o[i]], rl)
+            memcpy(r.qual, &q[o[i]], rl)
+            for k in range(rl):
+                if r.qual[k] < 5: r.nQualsBelow5 += 1
+                if r.qual[k] < 10: r.nQualsBelow10 += 1
+                if r.qual[k] < 15: r.nQualsBelow15 += 1
+                if r.qual[k] < 20: r.nQualsBelow20 += 1
+            r.pos = p[i]; r.rlen = rl; r.mapq = m[i]
+            nc = <int>(co[i + 1] - co[i])
+            r.cigarLen = nc
+            r.cigarOps = <int*>malloc((nc + 1) * sizeof(int))
+            r.cigarLens = <int*>malloc((nc + 1) * sizeof(int))
+            r.end = r.pos
+            for k in range(nc):
+                r.cigarOps[k] = cg[co[i] + k] & 0xf
+                r.cigarLens[k] = cg[co[i] + k] >> 4
+                if r.cigarOps[k] == 0 or r.cigarOps[k] == 2 or r.cigarOps[k] == 3:
+                    r.end += r.cigarLens[k]                          # samtoolsWrapper.pyx:773-774
+            r.isReverse = (fl[i] & 0x10) != 0
+            r.isDuplicate = (fl[i] & 0x400) != 0
+            r.isUnMapped = (fl[i] & 0x4) != 0
+            r.insertSize = isz[i]
+            r.mateIsUnmapped = (fl[i] & 0x8) != 0
+            r.mateIsReverse = (fl[i] & 0x20) != 0
+            r.matePos = mp[i]
+            r.isReadOne = (fl[i] & 0x40) != 0
+            r.isPaired = (fl[i] & 0x1) != 0
+            last = self.cReads[count - 1] if count > 0 else NULL
+            if not checkAndTrimRead(r, last, maxBadQualBases, minGoodQualBases):
+                free(r.seq); free(r.qual); free(r.cigarOps); free(r.cigarLens); free(r)
+                continue
+            if count > 0 and r.pos < self.cReads[count - 1].pos:
+                free(r.seq); free(r.qual); free(r.cigarOps); free(r.cigarLens); free(r)
+                self.nReads = count
+                raise ValueError("records are not sorted by position")
+            if r.end - r.pos > self.longestRead:
+                self.longestRead = r.end - r.pos
+            self.cReads[count] = r
+            count += 1
+            if count > maxReads:                                     # cwindow.pyx:221-223
+                break
+        self.nReads = count
+        self.start = self.cReads
+        self.end = self.cReads + count
+        self.windowStart = self.cReads
+        self.windowEnd = self.cReads + count
+        return self
+
     def __dealloc__(self):
         cdef int i
         if self.cReads != NULL:
             for i in range(self.nReads):
                 free(self.cReads[i].seq)
                 free(self.cReads[i].qual)
+                free(self.cReads[i].cigarOps)
+                free(self.cReads[i].cigarLens)
                 free(self.cReads[i])
             free(self.cReads)
+
+    def readInfo(self, int i):
+        """(pos, end, rlen, mapq, isReverse, qualities) of buffered read i -- for tests"""
+        cdef cAlignedRead* r = self.cReads[i]
+        return (r.pos, r.end, r.rlen, r.mapq, r.isReverse, bytes(r.qual[:r.rlen]))
 
     cdef setWindowPointers(self, int start, int end):
         """platypus/cwindow.pyx:242-267: reads with pos in [max(1, start - longestRead), end),

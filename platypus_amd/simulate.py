@@ -1,0 +1,134 @@
+"""A small diploid read simulator for tests and end-to-end timing: a random reference,
+planted SNPs / insertions / deletions (heterozygous or homozygous), single-end reads drawn from
+the two mutated copies with their true alignment (position + CIGAR), substitution errors and
+per-base qualities.  Output is the packed record layout `bamReadBuffer.fromAlignments` takes."""
+import numpy as np
+
+ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def random_genome(rng, length, homopolymers=0):
+    g = ACGT[rng.integers(0, 4, length)].copy()
+    for _ in range(homopolymers):
+        p = int(rng.integers(200, length - 200))
+        g[p:p + int(rng.integers(5, 15))] = ACGT[rng.integers(0, 4)]
+    return g.tobytes()
+
+
+def plant_variants(rng, genome, n, margin=300, spacing=120, indel_frac=0.3):
+    """n variants at least `spacing` apart: (pos, removed, added, genotype) with the package's
+    conventions (SNP at its base; insertion after the base at pos; deletion of the bases after pos),
+    genotype 1 = heterozygous, 2 = homozygous."""
+    out, pos = [], margin
+    while len(out) < n and pos < len(genome) - margin:
+        pos += int(rng.integers(spacing, 2 * spacing))
+        if pos >= len(genome) - margin:
+            break
+        gt = 1 if rng.random() < 0.6 else 2
+        if rng.random() < indel_frac:
+            k = int(rng.integers(1, 5))
+            if rng.random() < 0.5:
+                ins = ACGT[rng.integers(0, 4, k)].tobytes()
+                if ins[0:1] == genome[pos + 1:pos + 2] or ins[-1:] == genome[pos:pos + 1]:
+                    continue                              # would not be left-aligned: keep the test's truth simple
+                out.append((pos, b"", ins, gt))
+            else:
+                rem = genome[pos + 1:pos + 1 + k]
+                if genome[pos:pos + 1] == rem[-1:] or genome[pos + 1 + k:pos + 2 + k] == rem[0:1]:
+                    continue
+                out.append((pos, rem, b"", gt))
+        else:
+            ref = genome[pos:pos + 1]
+            alt = [b for b in b"ACGT" if b != ref[0]][int(rng.integers(0, 3))]
+            out.append((pos, ref, bytes([alt]), gt))
+    return out
+
+
+def _copy(genome, variants, which):
+    """mutated copy + segments (ref_start, hap_start, length, op) with op in 'M', 'I', 'D'"""
+    seq, segs, rp = [], [], 0
+    hp = 0
+    for pos, rem, add, gt in variants:
+        if gt == 1 and which == 1:
+            continue
+        if len(rem) == len(add):                          # SNP
+            n = pos - rp
+            if n > 0:
+                segs.append((rp, hp, n, "M")); seq.append(genome[rp:pos]); hp += n
+            segs.append((pos, hp, len(add), "M")); seq.append(add); hp += len(add)
+            rp = pos + len(rem)
+        else:
+            n = pos + 1 - rp
+            segs.append((rp, hp, n, "M")); seq.append(genome[rp:pos + 1]); hp += n
+            rp = pos + 1
+            if add:
+                segs.append((rp, hp, len(add), "I")); seq.append(add); hp += len(add)
+            else:
+                segs.append((rp, hp, len(rem), "D")); rp += len(rem)
+    n = len(genome) - rp
+    segs.append((rp, hp, n, "M")); seq.append(genome[rp:]); hp += n
+    return b"".join(seq), segs
+
+
+def simulate_reads(rng, genome, variants, coverage=30, read_len=100, error_rate=0.005, chrom=b"sim"):
+    """dict of packed record arrays, sorted by position"""
+    copies = [_copy(genome, variants, w) for w in (0, 1)]
+    n_reads = int(coverage * len(genome) / read_len)
+    recs = []
+    for _ in range(n_reads):
+        seq, segs = copies[int(rng.integers(0, 2))]
+        hs = int(rng.integers(0, len(seq) - read_len))
+        he = hs + read_len
+        cigar, pos = [], None
+        for rs, hps, n, op in segs:
+            if op == "D":
+                if pos is not None and hps > hs and hps < he:
+                    cigar.append((2, n))
+                continue
+            lo, hi = max(hs, hps), min(he, hps + n)
+            if lo >= hi:
+                continue
+            if op == "M":
+                if pos is None:
+                    pos = rs + (lo - hps)
+                cigar.append((0, hi - lo))
+            else:
+                if pos is None:                            # read starts inside an insertion: soft clip it
+                    cigar.append((4, hi - lo))
+                else:
+                    cigar.append((1, hi - lo))
+        if pos is None:
+            continue
+        while cigar and cigar[-1][0] in (1, 2):             # an alignment does not end with an indel
+            op, n = cigar.pop()
+            if op == 1:
+                cigar.append((4, n))
+                break
+        merged = []
+        for op, n in cigar:
+            if merged and merged[-1][0] == op:
+                merged[-1] = (op, merged[-1][1] + n)
+            else:
+                merged.append((op, n))
+        s = np.frombuffer(seq[hs:he], dtype=np.uint8).copy()
+        q = rng.integers(25, 41, read_len).astype(np.uint8)
+        err = rng.random(read_len) < error_rate
+        s[err] = ACGT[rng.integers(0, 4, int(err.sum()))]
+        q[err] = rng.integers(5, 25, int(err.sum()))
+        flag = 0x10 if rng.random() < 0.5 else 0
+        recs.append((pos, s, q, flag, merged))
+    recs.sort(key=lambda r: r[0])
+    off = np.concatenate([[0], np.cumsum([len(r[1]) for r in recs])]).astype(np.int64)
+    cig = [((n << 4) | op) for r in recs for op, n in r[4]]
+    coff = np.concatenate([[0], np.cumsum([len(r[4]) for r in recs])]).astype(np.int64)
+    return dict(chrom=chrom, seq=np.concatenate([r[1] for r in recs]), qual=np.concatenate([r[2] for r in recs]),
+                off=off, pos=np.array([r[0] for r in recs], dtype=np.int32),
+                mapq=np.full(len(recs), 60, dtype=np.int32), flag=np.array([r[3] for r in recs], dtype=np.int32),
+                cigar=np.array(cig, dtype=np.uint32), cigarOff=coff)
+
+
+def buffer_of(reads, start, end, **kw):
+    from platypus_amd import cwindow
+    return cwindow.bamReadBuffer.fromAlignments(reads["chrom"], start, end, reads["seq"], reads["qual"], reads["off"],
+                                                reads["pos"], reads["mapq"], reads["flag"], reads["cigar"],
+                                                reads["cigarOff"], **kw)

@@ -102,3 +102,112 @@ cdef class Variant:
 
     def __repr__(self):
         return self.__str__()
+
+
+from platypus_amd.samtoolsWrapper cimport cAlignedRead
+from platypus_amd.cwindow cimport bamReadBuffer
+
+
+cdef class VariantCandidateGenerator:
+    """Variant candidates from the CIGAR strings and mismatches of buffered reads
+    (platypus/variant.pyx:253-615): insertions and deletions flanked by a match of at least
+    minFlank bases, and mismatching bases of quality >= minBaseQual inside matches of at least
+    minFlank bases; equal candidates are merged and their support counted."""
+    cdef dict variantHeap
+    cdef object refFile
+    cdef bytes rname
+    cdef bytes pyRefSeq
+    cdef char* refSeq
+    cdef int refSeqStart
+    cdef int refSeqEnd
+    cdef int minMapQual, minBaseQual, minFlank, genSNPs, genIndels
+
+    def __init__(self, tuple region, refFile, int minMapQual=20, int minFlank=3, int minBaseQual=20,
+                 int genSNPs=1, int genIndels=1):
+        self.variantHeap = {}
+        self.refFile = refFile
+        self.rname = region[0]
+        self.refSeqStart = max(1, region[1] - 2000)                                    # variant.pyx:278-281
+        self.refSeqEnd = min(region[2] + 2000, refFile.refs[region[0]].SeqLength)
+        self.pyRefSeq = refFile.getSequence(self.rname, self.refSeqStart, self.refSeqEnd)
+        self.refSeq = self.pyRefSeq
+        self.minMapQual = minMapQual
+        self.minBaseQual = minBaseQual
+        self.minFlank = minFlank
+        self.genSNPs = genSNPs
+        self.genIndels = genIndels
+
+    cdef addVariantToList(self, Variant var):
+        cdef Variant theVar = self.variantHeap.get(var)
+        if theVar is None:
+            self.variantHeap[var] = var
+        else:
+            theVar.addVariant(var)
+
+    cdef getSnpCandidatesFromReadSegment(self, cAlignedRead* read, int readStart, int readOffset, int refOffset,
+                                         int lenSeqToCheck):
+        """variant.pyx:309-365"""
+        cdef int index, readIndex, refIndex, baseQual
+        cdef int nRef = <int>len(self.pyRefSeq)
+        cdef char readChar, refChar
+        for index in range(lenSeqToCheck):
+            readIndex = index + readOffset
+            refIndex = (index + refOffset + readStart) - self.refSeqStart
+            if refIndex < 0 or refIndex >= nRef or readIndex >= read.rlen:
+                continue                                   # beyond the cached reference: nothing to compare with
+            readChar = read.seq[readIndex]
+            refChar = self.refSeq[refIndex]
+            baseQual = read.qual[readIndex]
+            if readChar != refChar and readChar != b'N' and refChar != b'N' and baseQual >= self.minBaseQual:
+                self.addVariantToList(Variant(self.rname, refIndex + self.refSeqStart, bytes([refChar]),
+                                              bytes([readChar]), 1, 0 if read.isReverse else 1, read.mapq,
+                                              baseQual, readIndex + 1))
+
+    cdef getVariantCandidatesFromSingleRead(self, cAlignedRead* read):
+        """variant.pyx:367-474"""
+        cdef int readStart = read.pos, mapQ = read.mapq
+        cdef int flag, length, refOffset = 0, readOffset = 0, cigarIndex
+        cdef int cigarLength = read.cigarLen
+        cdef int nFwd = 0 if read.isReverse else 1
+        cdef bint flanked
+        for cigarIndex in range(cigarLength):
+            flag = read.cigarOps[cigarIndex]
+            length = read.cigarLens[cigarIndex]
+            flanked = ((cigarIndex > 0 and read.cigarOps[cigarIndex - 1] == 0 and read.cigarLens[cigarIndex - 1] >= self.minFlank)
+                       or (cigarIndex < cigarLength - 1 and read.cigarOps[cigarIndex + 1] == 0
+                           and read.cigarLens[cigarIndex + 1] >= self.minFlank))
+            if flag == 1 and self.genIndels:                               # insertion
+                if flanked:
+                    inserted = bytes(read.seq[readOffset:readOffset + length])
+                    if inserted.count(b"N") == 0:
+                        self.addVariantToList(Variant(self.rname, readStart + refOffset - 1, b"", inserted, 1, nFwd,
+                                                      mapQ, read.qual[readOffset], readOffset + 1))
+                readOffset += length
+            elif flag == 2:                                                # deletion
+                if flanked:
+                    deleted = self.refFile.getSequence(self.rname, readStart + refOffset, readStart + refOffset + length)
+                    if deleted.count(b"N") == 0 and self.genIndels:
+                        self.addVariantToList(Variant(self.rname, readStart + refOffset - 1, deleted, b"", 1, nFwd,
+                                                      mapQ, read.qual[readOffset], readOffset + 1))
+                refOffset += length
+            elif flag == 0:                                                # match
+                if length >= self.minFlank and self.genSNPs:
+                    self.getSnpCandidatesFromReadSegment(read, readStart, readOffset, refOffset, length)
+                readOffset += length
+                refOffset += length
+            elif flag == 3:                                                # skipped reference (as the reference: both advance)
+                readOffset += length
+                refOffset += length
+            elif flag == 4:                                                # soft clip
+                readOffset += length
+            # hard clip, padding, others: nothing (variant.pyx:464-474); an insertion with
+            # genIndels == 0 falls through here as well and leaves readOffset alone, as it does there
+
+    def addCandidatesFromBuffer(self, bamReadBuffer buf):
+        """variant.pyx:600-612 over the whole buffer"""
+        cdef int i
+        for i in range(buf.nReads):
+            self.getVariantCandidatesFromSingleRead(buf.cReads[i])
+
+    def getCandidates(self):
+        return sorted(self.variantHeap.values())

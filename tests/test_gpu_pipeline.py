@@ -1,0 +1,94 @@
+"""A whole region call on simulated data: reads with true CIGARs -> candidates -> windows -> haplotypes ->
+ONE alignment launch + ONE genotype/EM launch -> calls.  The truth is known by construction."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_planted_variants_are_called_with_their_genotypes():
+    from platypus_amd import calign, pipeline, simulate
+    from platypus_amd.fastafile import FastaFile
+    rng = np.random.default_rng(7)
+    G = 24000
+    genome = simulate.random_genome(rng, G)
+    truth = simulate.plant_variants(rng, genome, 70)
+    reads = simulate.simulate_reads(rng, genome, truth, coverage=30, read_len=100, error_rate=0.005)
+    fa = FastaFile(sequences={b"sim": genome})
+    buf = simulate.buffer_of(reads, 0, G)
+    stats = {}
+    calls = pipeline.callRegion(b"sim", 0, G, [buf], fa, pipeline.Options(rlen=100), stats=stats)
+    assert stats["called_windows"] >= len(truth) - 2 and stats["windows"] >= stats["called_windows"]
+    called = {}
+    for c in calls:
+        for vi, v in enumerate(c.variants):
+            called[(v.refPos, v.removed, v.added)] = (c, vi)
+    missed = [t for t in truth if (t[0], t[1], t[2]) not in called]
+    assert len(missed) <= 1, missed
+    wrong_gt = 0
+    for pos, rem, add, gt in truth:
+        if (pos, rem, add) not in called:
+            continue
+        c, vi = called[(pos, rem, add)]
+        assert int(c.PP[vi]) >= 20
+        alleles = sorted(c.GT[0].split("/"))
+        want = ["0", str(vi + 1)] if gt == 1 else [str(vi + 1), str(vi + 1)]
+        wrong_gt += alleles != want
+        if len(c.variants) == 1:
+            gl = c.GL[0]
+            assert gl != [-1, -1, -1] and max(gl) == gl[gt]          # AA, AB, BB: the true genotype is the most likely
+            assert gl[0] < gl[gt] - 5
+            assert c.nReads[0] > 5 and 0 <= c.GQ[0] <= 100
+        fr = float(c.FR[vi])
+        assert (0.3 < fr < 0.7) if gt == 1 else fr > 0.9
+    assert wrong_gt <= 1
+    false_pos = [k for k in called if k not in {(t[0], t[1], t[2]) for t in truth}]
+    assert len(false_pos) <= 2, false_pos
+    calign.closeDevice()
+
+
+def test_two_samples_and_a_crowded_window():
+    """two samples with different genotypes; a window with more candidates than maxVariants goes through the
+    posterior pre-filter (variantcaller.pyx:142-166)"""
+    from platypus_amd import calign, pipeline, simulate
+    from platypus_amd.fastafile import FastaFile
+    rng = np.random.default_rng(11)
+    G = 6000
+    genome = simulate.random_genome(rng, G)
+    snp = lambda p: (p, genome[p:p + 1], b"A" if genome[p:p + 1] != b"A" else b"C")
+    shared = [snp(1000) + (2,), snp(2000) + (1,)]
+    only_b = [snp(3000) + (2,)]
+    crowded = [snp(4000 + 3 * i) + (2,) for i in range(4)]          # four SNPs within 10 bases
+    reads_a = simulate.simulate_reads(rng, genome, sorted(shared + crowded), coverage=25, read_len=80)
+    reads_b = simulate.simulate_reads(rng, genome, sorted(shared + only_b + crowded), coverage=25, read_len=80)
+    fa = FastaFile(sequences={b"sim": genome})
+    bufs = [simulate.buffer_of(reads_a, 0, G), simulate.buffer_of(reads_b, 0, G)]
+    opts = pipeline.Options(rlen=80, maxVariants=3)
+    calls = pipeline.callRegion(b"sim", 0, G, bufs, fa, opts)
+    by_pos = {c.pos: c for c in calls}
+    assert all(sorted(by_pos[1000].GT[i].split("/")) == ["1", "1"] for i in (0, 1))
+    assert sorted(by_pos[2000].GT[0].split("/")) == ["0", "1"] and sorted(by_pos[2000].GT[1].split("/")) == ["0", "1"]
+    assert sorted(by_pos[3000].GT[0].split("/")) == ["0", "0"] and sorted(by_pos[3000].GT[1].split("/")) == ["1", "1"]
+    # the SNPs at 4000, 4003, 4006, 4009 are windows of their own (maxPos == refPos for SNPs, variant.pyx:48-49);
+    # each window's single-SNP haplotype still mismatches the reads at the other three, the aligner explains such
+    # a cluster about as cheaply either way, and the inner ones fall below minPosterior -- the model's behaviour
+    assert 4000 in by_pos and 4009 in by_pos
+    assert all(int(pp) < 100 for p in (4000, 4009) for pp in by_pos[p].PP)
+    # a crowded window: a deletion, a SNP on its last base, a second deletion starting there and a SNP on ITS
+    # last base chain into one window of four candidates (each reaches the next one's position); with
+    # maxVariants = 3 the window first goes through the posterior pre-filter.  Truth: the first deletion and
+    # the last SNP (both homozygous in both samples); the two in between are spurious candidates.
+    from platypus_amd.variant import Variant
+    dele = (4500, genome[4501:4504], b"", 2)
+    last = snp(4506) + (2,)
+    reads_c = simulate.simulate_reads(rng, genome, [dele, last], coverage=30, read_len=80)
+    bufs_c = [simulate.buffer_of(reads_c, 0, G)]
+    cands = sorted([Variant(b"sim", 4500, dele[1], b"", 10, 5), Variant(b"sim", 4503, *snp(4503)[1:], 3, 2),
+                    Variant(b"sim", 4503, genome[4504:4507], b"", 3, 1), Variant(b"sim", 4506, last[1], last[2], 10, 5)])
+    wins = list(pipeline.WindowGenerator().WindowsAndVariants(b"sim", 4400, 4600, cands, opts))
+    assert len(wins) == 1 and len(wins[0]["variants"]) == 4
+    calls2 = pipeline.callRegion(b"sim", 4400, 4600, bufs_c, fa, opts, variants=cands)
+    got = {(v.refPos, v.removed, v.added) for c in calls2 for v in c.variants}
+    assert got == {(4500, dele[1], b""), (4506, last[1], last[2])}
+    assert all(sorted(c.GT[0].split("/")) == ["1", "1"] for c in calls2)
+    calign.closeDevice()
