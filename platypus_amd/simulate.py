@@ -73,14 +73,19 @@ def _copy(genome, variants, which):
 def simulate_reads(rng, genome, variants, coverage=30, read_len=100, error_rate=0.005, chrom=b"sim"):
     """dict of packed record arrays, sorted by position"""
     copies = [_copy(genome, variants, w) for w in (0, 1)]
+    starts = [np.array([sg[1] for sg in segs]) for _, segs in copies]     # haplotype start of every segment
     n_reads = int(coverage * len(genome) / read_len)
     recs = []
-    for _ in range(n_reads):
-        seq, segs = copies[int(rng.integers(0, 2))]
+    which = rng.integers(0, 2, n_reads)
+    for k in range(n_reads):
+        seq, segs = copies[which[k]]
         hs = int(rng.integers(0, len(seq) - read_len))
         he = hs + read_len
         cigar, pos = [], None
-        for rs, hps, n, op in segs:
+        first = max(0, int(np.searchsorted(starts[which[k]], hs, side="right")) - 2)
+        for rs, hps, n, op in segs[first:]:
+            if hps >= he:
+                break
             if op == "D":
                 if pos is not None and hps > hs and hps < he:
                     cigar.append((2, n))
