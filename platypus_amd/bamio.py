@@ -1,0 +1,272 @@
+"""BAM files for the region caller: BGZF blocks, header, region fetch through the linear index of a
+.bai file (or a scan when there is none), and a plain writer (BAM + BAI) used by the simulator and
+the tests.  Replaces what the reference gets from its vendored samtools through
+platypus/samtoolsWrapper.pyx (Samfile.fetch, createRead) on the read side; record decoding is in
+platypus_amd/cbam.pyx."""
+import os
+import struct
+import zlib
+
+import numpy as np
+
+from platypus_amd import cbam
+
+_EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+
+
+def _read_block(f):
+    """one BGZF block at the file position: (uncompressed bytes, compressed size) or (b'', 0) at EOF"""
+    head = f.read(18)
+    if len(head) < 18:
+        return b"", 0
+    if head[:4] != b"\x1f\x8b\x08\x04":
+        raise IOError("not a BGZF block")
+    xlen = struct.unpack_from("<H", head, 10)[0]
+    extra = head[12:18] + f.read(xlen - 6)
+    bsize = None
+    k = 0
+    while k + 4 <= len(extra):
+        si1, si2, slen = extra[k], extra[k + 1], struct.unpack_from("<H", extra, k + 2)[0]
+        if si1 == 66 and si2 == 67:
+            bsize = struct.unpack_from("<H", extra, k + 4)[0]
+        k += 4 + slen
+    if bsize is None:
+        raise IOError("BGZF block without a BC field")
+    body = f.read(bsize + 1 - 12 - xlen)
+    return zlib.decompress(body[:-8], -15), bsize + 1
+
+
+class BamReader(object):
+    def __init__(self, fileName, indexName=None):
+        self.fileName = fileName
+        self.f = open(fileName, "rb")
+        data, pos = b"", 0
+        # header: may span blocks
+        def need(n):
+            nonlocal data
+            while len(data) - pos < n:
+                blk, size = _read_block(self.f)
+                if not size:
+                    raise IOError("truncated BAM header")
+                data += blk
+        need(12)
+        if data[:4] != b"BAM\x01":
+            raise IOError("%s is not a BAM file" % fileName)
+        l_text = struct.unpack_from("<i", data, 4)[0]
+        need(12 + l_text)
+        self.text = data[8:8 + l_text]
+        pos = 8 + l_text
+        need(4)
+        n_ref = struct.unpack_from("<i", data, pos)[0]
+        pos += 4
+        self.refs, self.lengths = [], []
+        for _ in range(n_ref):
+            need(4)
+            ln = struct.unpack_from("<i", data, pos)[0]
+            need(8 + ln)
+            self.refs.append(data[pos + 4:pos + 4 + ln - 1])
+            self.lengths.append(struct.unpack_from("<i", data, pos + 4 + ln)[0])
+            pos += 8 + ln
+        # virtual offset of the first alignment
+        self._first = (self.f.tell(), None) if pos == len(data) else None
+        self._header_tail = data[pos:]
+        self._after_header = self.f.tell()
+        self.sample = None
+        for line in self.text.split(b"\n"):
+            if line.startswith(b"@RG"):
+                for fld in line.split(b"\t"):
+                    if fld.startswith(b"SM:"):
+                        self.sample = fld[3:].decode()
+        self.linear = None
+        index = indexName or (fileName + ".bai")
+        if not os.path.exists(index) and os.path.exists(fileName[:-4] + ".bai"):
+            index = fileName[:-4] + ".bai"
+        if os.path.exists(index):
+            self.linear = _read_linear_index(index)
+
+    def close(self):
+        self.f.close()
+
+    def fetch(self, chrom, start, end):
+        """packed records of `chrom` overlapping [start, end) (0-based), in position order"""
+        chrom = chrom if isinstance(chrom, bytes) else chrom.encode()
+        if chrom not in self.refs:
+            raise KeyError("no reference %r in %s" % (chrom, self.fileName))
+        rid = self.refs.index(chrom)
+        if self.linear is not None and rid < len(self.linear) and len(self.linear[rid]):
+            lin = self.linear[rid]
+            voff = lin[min(max(start, 0) >> 14, len(lin) - 1)]
+            if voff == 0:                               # no alignment recorded for that window: look further left
+                k = min(start >> 14, len(lin) - 1)
+                while k > 0 and lin[k] == 0:
+                    k -= 1
+                voff = lin[k]
+            if voff == 0:
+                voff = None
+        else:
+            voff = None
+        if voff is None:
+            self.f.seek(self._after_header)
+            buf = bytearray(self._header_tail)
+        else:
+            self.f.seek(voff >> 16)
+            blk, _ = _read_block(self.f)
+            buf = bytearray(blk[voff & 0xffff:])
+        parts = []
+        while True:
+            arrays, used, done = cbam.parseRecords(np.frombuffer(bytes(buf), dtype=np.uint8), rid, start, end)
+            if len(arrays["pos"]):
+                parts.append(arrays)
+            del buf[:used]
+            if done:
+                break
+            grew = False
+            for _ in range(64):                          # up to 4 MiB per round
+                blk, size = _read_block(self.f)
+                if not size:
+                    break
+                buf += blk
+                grew = True
+            if not grew:
+                break
+        return _concat(parts)
+
+
+def _concat(parts):
+    if not parts:
+        z = np.zeros(0, dtype=np.int32)
+        return dict(seq=np.zeros(0, np.uint8), qual=np.zeros(0, np.uint8), off=np.zeros(1, np.int64), pos=z, mapq=z,
+                    flag=z, cigar=np.zeros(0, np.uint32), cigarOff=np.zeros(1, np.int64), insertSize=z, matePos=z)
+    out = {}
+    for k in ("seq", "qual", "pos", "mapq", "flag", "cigar", "insertSize", "matePos"):
+        out[k] = np.concatenate([p[k] for p in parts])
+    for k, base in (("off", "seq"), ("cigarOff", "cigar")):
+        offs, at = [np.zeros(1, np.int64)], 0
+        for p in parts:
+            offs.append(p[k][1:] + at)
+            at += len(p[base])
+        out[k] = np.concatenate(offs)
+    return out
+
+
+def _read_linear_index(path):
+    with open(path, "rb") as f:
+        d = f.read()
+    if d[:4] != b"BAI\x01":
+        raise IOError("%s is not a BAI file" % path)
+    n_ref, p = struct.unpack_from("<i", d, 4)[0], 8
+    out = []
+    for _ in range(n_ref):
+        n_bin = struct.unpack_from("<i", d, p)[0]
+        p += 4
+        for _ in range(n_bin):
+            n_chunk = struct.unpack_from("<i", d, p + 4)[0]
+            p += 8 + 16 * n_chunk
+        n_intv = struct.unpack_from("<i", d, p)[0]
+        p += 4
+        out.append(np.frombuffer(d, dtype="<u8", count=n_intv, offset=p).astype(np.int64))
+        p += 8 * n_intv
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+def _reg2bin(beg, end):
+    end -= 1
+    if beg >> 14 == end >> 14:
+        return ((1 << 15) - 1) // 7 + (beg >> 14)
+    if beg >> 17 == end >> 17:
+        return ((1 << 12) - 1) // 7 + (beg >> 17)
+    if beg >> 20 == end >> 20:
+        return ((1 << 9) - 1) // 7 + (beg >> 20)
+    if beg >> 23 == end >> 23:
+        return ((1 << 6) - 1) // 7 + (beg >> 23)
+    if beg >> 26 == end >> 26:
+        return ((1 << 3) - 1) // 7 + (beg >> 26)
+    return 0
+
+
+def write_bam(path, refs, reads, sample="sample", names=None):
+    """A coordinate-sorted BAM with its .bai from packed records of ONE reference (refs: list of
+    (name, length); `reads` as produced by platypus_amd.simulate or BamReader.fetch, plus optional
+    'refID').  For tests and simulations: no tags, read names r<i>."""
+    text = ("@HD\tVN:1.0\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % (n.decode() if isinstance(n, bytes) else n, l)
+                                                       for n, l in refs) +
+            "@RG\tID:1\tSM:%s\n" % sample).encode()
+    head = b"BAM\x01" + struct.pack("<i", len(text)) + text + struct.pack("<i", len(refs))
+    for n, l in refs:
+        n = n if isinstance(n, bytes) else n.encode()
+        head += struct.pack("<i", len(n) + 1) + n + b"\x00" + struct.pack("<i", l)
+    rid = int(reads.get("refID", 0))
+    code = np.zeros(256, dtype=np.uint8)
+    for i, ch in enumerate(b"=ACMGRSVTWYHKDBN"):
+        code[ch] = i
+    n = len(reads["pos"])
+    isz = reads.get("insertSize", np.zeros(n, np.int32))
+    mpos = reads.get("matePos", np.full(n, -1, np.int32))
+    out = open(path, "wb")
+    block, coff = bytearray(head), 0
+    bins, linear = {}, {}
+
+    def flush():
+        nonlocal block, coff
+        while block:
+            chunk, block = bytes(block[:0xff00]), block[0xff00:]
+            comp = zlib.compressobj(1, zlib.DEFLATED, -15)
+            body = comp.compress(chunk) + comp.flush()
+            blk = (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(body) + 25) + body +
+                   struct.pack("<II", zlib.crc32(chunk) & 0xffffffff, len(chunk)))
+            out.write(blk)
+            coff += len(blk)
+
+    flush()                                              # header in blocks of its own
+    for i in range(n):
+        s0, s1 = int(reads["off"][i]), int(reads["off"][i + 1])
+        c0, c1 = int(reads["cigarOff"][i]), int(reads["cigarOff"][i + 1])
+        lseq = s1 - s0
+        cig = reads["cigar"][c0:c1].astype("<u4")
+        pos = int(reads["pos"][i])
+        end = pos + int(sum(int(w) >> 4 for w in cig if (int(w) & 0xf) in (0, 2, 3)))
+        name = (names[i] if names is not None else "r%d" % i).encode() + b"\x00"
+        codes = code[reads["seq"][s0:s1]]
+        if lseq & 1:
+            codes = np.append(codes, 0)
+        packed = ((codes[0::2] << 4) | codes[1::2]).astype(np.uint8).tobytes()
+        b = _reg2bin(pos, max(end, pos + 1))
+        rec = struct.pack("<iiIIiiii", rid, pos, (b << 16) | (int(reads["mapq"][i]) << 8) | len(name),
+                          (int(reads["flag"][i]) << 16) | len(cig), lseq, rid if int(mpos[i]) >= 0 else -1, int(mpos[i]),
+                          int(isz[i])) + name + cig.tobytes() + packed + reads["qual"][s0:s1].tobytes()
+        if len(block) + len(rec) + 4 > 0xff00:
+            flush()
+        voff = (coff << 16) | len(block)
+        block += struct.pack("<i", len(rec)) + rec
+        vend = (coff << 16) | len(block)
+        bins.setdefault(b, []).append([voff, vend])
+        for w in range(pos >> 14, (max(end, pos + 1) - 1 >> 14) + 1):
+            if w not in linear:
+                linear[w] = voff
+    flush()
+    out.write(_EOF)
+    out.close()
+    with open(path + ".bai", "wb") as f:
+        f.write(b"BAI\x01" + struct.pack("<i", len(refs)))
+        for r in range(len(refs)):
+            if r != rid:
+                f.write(struct.pack("<ii", 0, 0))
+                continue
+            f.write(struct.pack("<i", len(bins)))
+            for b in sorted(bins):
+                merged = []
+                for beg, end in bins[b]:
+                    if merged and merged[-1][1] >> 16 == beg >> 16:
+                        merged[-1][1] = end
+                    else:
+                        merged.append([beg, end])
+                f.write(struct.pack("<Ii", b, len(merged)))
+                for beg, end in merged:
+                    f.write(struct.pack("<QQ", beg, end))
+            n_intv = (max(linear) + 1) if linear else 0
+            f.write(struct.pack("<i", n_intv))
+            last = 0
+            for w in range(n_intv):
+                last = linear.get(w, last)
+                f.write(struct.pack("<Q", last))

@@ -11,7 +11,7 @@ import sysconfig
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-MODULES = ["variant", "calign", "cwindow", "chaplotype", "cgenotype", "cpopulation"]
+MODULES = ["cbam", "variant", "calign", "cwindow", "chaplotype", "cgenotype", "cpopulation"]
 PXD = ["samtoolsWrapper.pxd", "platgpu.pxd", "calign.pxd", "cwindow.pxd", "chaplotype.pxd", "cgenotype.pxd", "cpopulation.pxd", "variant.pxd"]
 
 

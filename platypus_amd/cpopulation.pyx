@@ -280,6 +280,23 @@ cdef class WindowBatch:
         self.windows.append((haplotypes, readBuffers, counts, ptrs))
         return len(self.windows) - 1
 
+    def coverage(self, int w, int varPos):
+        """(TC, TCR, TCF) of cpopulation.pyx:322-346: the window's reads, over all individuals, that
+        span position varPos (pos <= varPos <= end), and how many of them are on the reverse /
+        forward strand."""
+        cdef cAlignedRead* rd
+        cdef size_t p
+        cdef int tc = 0, tcr = 0
+        for lst in self.windows[w][3]:
+            for q in lst:
+                p = q
+                rd = <cAlignedRead*>p
+                if rd.pos <= varPos and rd.end >= varPos:
+                    tc += 1
+                    if rd.isReverse:
+                        tcr += 1
+        return tc, tcr, tc - tcr
+
     def readCounts(self, int w):
         """reads per individual of window w"""
         return list(self.windows[w][2])

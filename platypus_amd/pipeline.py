@@ -198,8 +198,8 @@ def haplotypesInWindow(window, nReads, refFile, options):
 # ---------------------------------------------------------------------------------------------
 class Call(object):
     """What outputCallToVCF derives for one output position (variantcaller.pyx:302-436)."""
-    __slots__ = ("chrom", "pos", "variants", "posteriors", "PP", "FR", "TR", "NF", "NR", "qual", "GT", "GQ", "GL",
-                 "nReads")
+    __slots__ = ("chrom", "pos", "variants", "posteriors", "PP", "FR", "TR", "NF", "NR", "TC", "TCR", "TCF", "qual",
+                 "GT", "GQ", "GL", "nReads")
 
     def __repr__(self):
         return "Call(%s:%d %s PP=%s FR=%s GT=%s)" % (self.chrom.decode(), self.pos, self.variants, self.PP, self.FR,
@@ -324,6 +324,7 @@ def callRegion(chrom, start, end, readBuffers, refFile, options=None, variants=N
             c.TR = [v.nSupportingReads for v in vs]
             c.NF = [v.nFwdReads for v in vs]
             c.NR = [v.nRevReads for v in vs]
+            c.TC, c.TCR, c.TCF = batch.coverage(k, vs[0].refPos)       # of the line's first variant, variantcaller.pyx:329
             c.qual = max(int(pp) for pp in c.PP)
             c.GT, c.GQ, c.GL, c.nReads = [], [], [], []
             for ind, g in enumerate(pop.genotypeCalls):

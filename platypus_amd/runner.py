@@ -1,0 +1,121 @@
+"""Command line of the region caller: BAM files + indexed FASTA -> VCF, one worker process per GPU.
+
+    python -m platypus_amd.runner callVariants --bamFiles a.bam,b.bam --refFile ref.fa \\
+        [--regions chr:start-end,...] [--output AllVariants.vcf] [--nGPU 1] [options of Options]
+
+The scheduling is the reference's (platypus/runner.py:98-165): regions are cut into chunks of
+--processRegionSize, every chunk is called on its own into a temporary file and the files are
+concatenated in (chromosome, start) order.  Where the reference deals chunks to --nCPU worker
+processes, here they are dealt to --nGPU processes, each bound to one device; nothing is
+exchanged between them.  Inside a chunk reads are buffered --bufferSize bases at a time
+(platypus/variantcaller.pyx:229-233)."""
+import argparse
+import multiprocessing
+import os
+import sys
+import tempfile
+
+from platypus_amd import shard
+
+
+def parse_regions(text, fasta):
+    """platypus/bamfileutils.pyx:162-246 for 'chr', 'chr:start-end' lists; default: every sequence of the FASTA index"""
+    out = []
+    if not text:
+        for name, t in sorted(fasta.refs.items()):
+            out.append((name.decode(), None, t.SeqLength))
+        return out
+    for item in text.split(","):
+        if ":" in item:
+            chrom, span = item.split(":")
+            s, e = span.split("-")
+            out.append((chrom, int(s), int(e)))
+        else:
+            out.append((item, None, fasta.refs[item.encode()].SeqLength))
+    return out
+
+
+def call_chunk(chunk, args, out_path):
+    from platypus_amd import bamio, pipeline, simulate, vcfout
+    from platypus_amd.fastafile import FastaFile
+    chrom, start, end = chunk
+    fa = FastaFile(args.refFile, args.refFile + ".fai")
+    readers = [bamio.BamReader(b) for b in args.bamFiles.split(",")]
+    samples = [r.sample or os.path.basename(r.fileName) for r in readers]
+    opts = pipeline.Options(**{k: getattr(args, k) for k in vars(pipeline.Options()) if hasattr(args, k)})
+    n_calls = 0
+    with open(out_path, "w") as out:
+        out.write("\n".join(vcfout.header(samples, " ".join(sys.argv[1:]))) + "\n")
+        for s in range(start, end, args.bufferSize):
+            e = min(s + args.bufferSize, end)
+            bufs = []
+            for r in readers:
+                reads = r.fetch(chrom, s, e)
+                reads["chrom"] = chrom.encode()
+                bufs.append(simulate.buffer_of(reads, s, e, minMapQual=opts.minMapQual, maxReads=int(opts.maxReads),
+                                               minGoodQualBases=opts.minGoodQualBases, maxBadQualBases=opts.maxBadQualBases))
+            if sum(b.readCount for b in bufs) > opts.maxReads:            # variantcaller.pyx:84-88
+                continue
+            for c in pipeline.callRegion(chrom.encode(), s, e, bufs, fa, opts):
+                out.write(vcfout.record(c, fa) + "\n")
+                n_calls += 1
+    for r in readers:
+        r.close()
+    return n_calls
+
+
+def _worker(rank, chunks, args, tmpdir, queue):
+    os.environ["PLATGPU_DEVICE"] = str(rank)
+    total = 0
+    for ch in chunks:
+        total += call_chunk(ch, args, os.path.join(tmpdir, "output_temp_" + shard.region_name(ch)))
+    queue.put((rank, total))
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="platypus_amd.runner")
+    ap.add_argument("command", choices=["callVariants"])
+    ap.add_argument("--bamFiles", required=True)
+    ap.add_argument("--refFile", required=True)
+    ap.add_argument("--regions", default=None)
+    ap.add_argument("--output", "-o", default="AllVariants.vcf")
+    ap.add_argument("--nGPU", type=int, default=1)
+    ap.add_argument("--processRegionSize", type=int, default=1000000)
+    ap.add_argument("--bufferSize", type=int, default=1000000)
+    from platypus_amd import pipeline
+    for k, v in vars(pipeline.Options()).items():
+        ap.add_argument("--" + ("maxReadLength" if k == "rlen" else k), dest=k, type=type(v), default=v)
+    args = ap.parse_args(argv)
+    from platypus_amd.fastafile import FastaFile
+    fa = FastaFile(args.refFile, args.refFile + ".fai")
+    chunks = shard.split_regions(parse_regions(args.regions, fa), args.processRegionSize)
+    tmpdir = tempfile.mkdtemp(prefix="platypus_amd_")
+    per_rank = shard.assign(chunks, max(1, args.nGPU))
+    if args.nGPU <= 1:
+        for ch in chunks:
+            call_chunk(ch, args, os.path.join(tmpdir, "output_temp_" + shard.region_name(ch)))
+    else:
+        ctx = multiprocessing.get_context("spawn")      # a fresh process per device: nothing of the parent's GPU state
+        queue = ctx.Queue()
+        procs = [ctx.Process(target=_worker, args=(r, per_rank[r], args, tmpdir, queue)) for r in range(args.nGPU)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join()
+            if p.exitcode != 0:
+                raise SystemExit("a worker failed (exit code %s)" % p.exitcode)
+    parts = {}
+    for ch in chunks:
+        name = shard.region_name(ch)
+        with open(os.path.join(tmpdir, "output_temp_" + name)) as f:
+            parts[name] = f.read().splitlines()
+    with open(args.output, "w") as out:
+        out.write("\n".join(shard.merge_outputs(parts)) + "\n")
+    for ch in chunks:
+        os.remove(os.path.join(tmpdir, "output_temp_" + shard.region_name(ch)))
+    os.rmdir(tmpdir)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,69 @@
+"""VCF text for the calls of platypus_amd.pipeline: the line layout of the reference's writer
+(platypus/vcf.py:710-739 with the field order of format_formatdata, :297-328), REF/ALT by
+the rule of platypus/variantcaller.pyx:442-502.  INFO carries the fields this package computes
+(FR, PP, TR, NF, NR, TC, TCR, TCF); the reference's strand/allele-bias statistics and their
+filters (cpopulation.pyx:362-474) are not computed, so FILTER is always PASS."""
+import datetime
+
+INFO = [("FR", ".", "Float", "Estimated population frequency"),
+        ("PP", ".", "Float", "Posterior probability (phred scaled) that this variant segregates"),
+        ("TC", "1", "Integer", "Total coverage at this locus"),
+        ("TCR", "1", "Integer", "Total reverse strand coverage at this locus"),
+        ("TCF", "1", "Integer", "Total forward strand coverage at this locus"),
+        ("TR", ".", "Integer", "Total number of reads containing this variant"),
+        ("NF", ".", "Integer", "Total number of forward reads containing this variant"),
+        ("NR", ".", "Integer", "Total number of reverse reads containing this variant")]
+FORMAT = [("GT", "1", "String", "Unphased genotypes"),
+          ("GL", ".", "Float", "Genotype log-likelihoods (log10) for AA,AB and BB genotypes, where A = ref and B = variant. "
+                               "Only applicable for bi-allelic sites"),
+          ("GQ", "1", "Integer", "Genotype quality, as Phred score"),
+          ("NR", "1", "Integer", "Number of reads covering variant in this sample")]
+
+
+def header(samples, options_text=""):
+    lines = ["##fileformat=VCFv4.0", "##fileDate=%s" % datetime.date.today(),
+             "##source=platypus_amd (Platypus 0.1.5 calling model on MI355X)"]
+    if options_text:
+        lines.append("##platypusOptions=%s" % options_text)
+    for k, n, t, d in INFO:
+        lines.append('##INFO=<ID=%s,Number=%s,Type=%s,Description="%s">' % (k, n, t, d))
+    for k, n, t, d in FORMAT:
+        lines.append('##FORMAT=<ID=%s,Number=%s,Type=%s,Description="%s">' % (k, n, t, d))
+    lines.append("\t".join(["#CHROM", "POS", "ID", "REF", "ALT", "QUAL", "FILTER", "INFO", "FORMAT"] + list(samples)))
+    return lines
+
+
+def ref_and_alt(chrom, pos, variants, refFile):
+    """variantcaller.pyx:442-502"""
+    non_snp = any(v.nRemoved != 1 or v.nAdded != 1 for v in variants)
+    indel = any(v.nRemoved != v.nAdded for v in variants)
+    if not non_snp:
+        return refFile.getCharacter(chrom, pos), [v.added for v in variants]
+    rlen = max(v.nRemoved for v in variants)
+    ref = refFile.getSequence(chrom, pos, pos + rlen + (1 if indel else 0))
+    alts = []
+    for v in variants:
+        seq = bytearray(ref)
+        if v.nRemoved == v.nAdded:
+            seq[0:len(v.added)] = v.added
+        else:
+            seq[1:1 + v.nRemoved] = v.added
+        alts.append(bytes(seq))
+    return ref, alts
+
+
+def _num(x):
+    s = str(x)
+    return s[:-2] if s.endswith(".0") and isinstance(x, float) and False else s
+
+
+def record(call, refFile):
+    ref, alts = ref_and_alt(call.chrom, call.pos, call.variants, refFile)
+    info = dict(FR=call.FR, PP=call.PP, TR=call.TR, NF=call.NF, NR=call.NR, TC=[call.TC], TCR=[call.TCR], TCF=[call.TCF])
+    info_text = ";".join("%s=%s" % (k, ",".join(str(x) for x in info[k])) for k in sorted(info))
+    cols = [call.chrom.decode(), str(call.pos + 1), ".", ref.decode(), ",".join(a.decode() for a in alts),
+            str(call.qual), "PASS", info_text, "GT:GL:GQ:NR"]
+    for i in range(len(call.GT)):
+        cols.append("%s:%s:%s:%s" % (call.GT[i], ",".join(str(x) for x in call.GL[i]),
+                                     "." if call.GQ[i] == -1 else call.GQ[i], call.nReads[i]))
+    return "\t".join(cols)

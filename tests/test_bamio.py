@@ -1,0 +1,59 @@
+"""BAM writing and reading (BGZF blocks, header, records, .bai linear index) round trip, and region fetch
+against a direct selection of the overlapping records."""
+import gzip
+
+import numpy as np
+
+from platypus_amd import bamio, simulate
+
+
+def _ends(reads):
+    ends = reads["pos"].copy()
+    for i in range(len(ends)):
+        for w in reads["cigar"][reads["cigarOff"][i]:reads["cigarOff"][i + 1]]:
+            if (int(w) & 0xf) in (0, 2, 3):
+                ends[i] += int(w) >> 4
+    return ends
+
+
+def _select(reads, keep):
+    idx = np.flatnonzero(keep)
+    if len(idx) == 0:
+        return dict(pos=reads["pos"][:0])
+    out = {k: reads[k][idx] for k in ("pos", "mapq", "flag")}
+    out["seq"] = np.concatenate([reads["seq"][reads["off"][i]:reads["off"][i + 1]] for i in idx])
+    out["qual"] = np.concatenate([reads["qual"][reads["off"][i]:reads["off"][i + 1]] for i in idx])
+    out["off"] = np.concatenate([[0], np.cumsum(reads["off"][idx + 1] - reads["off"][idx])])
+    out["cigar"] = np.concatenate([reads["cigar"][reads["cigarOff"][i]:reads["cigarOff"][i + 1]] for i in idx])
+    out["cigarOff"] = np.concatenate([[0], np.cumsum(reads["cigarOff"][idx + 1] - reads["cigarOff"][idx])])
+    return out
+
+
+def test_bam_round_trip_and_region_fetch(tmp_path):
+    rng = np.random.default_rng(4)
+    G = 120000
+    genome = simulate.random_genome(rng, G)
+    truth = simulate.plant_variants(rng, genome, 60, spacing=900)
+    reads = simulate.simulate_reads(rng, genome, truth, coverage=6, read_len=75)
+    path = str(tmp_path / "s.bam")
+    bamio.write_bam(path, [(b"other", 500), (b"sim", G)], dict(reads, refID=1), sample="NA1")
+    assert gzip.open(path).read(4) == b"BAM\x01"                       # BGZF is valid multi-member gzip
+    rd = bamio.BamReader(path)
+    assert rd.refs == [b"other", b"sim"] and rd.lengths == [500, G] and rd.sample == "NA1"
+    ends = _ends(reads)
+    for (s, e) in [(0, G), (40000, 41000), (16384, 32768), (99990, 100010), (G - 50, G), (5, 6)]:
+        got = rd.fetch(b"sim", s, e)
+        want = _select(reads, (reads["pos"] < e) & (ends > s))
+        assert len(got["pos"]) == len(want["pos"])
+        for k in want:
+            assert np.array_equal(got[k], want[k]), (s, e, k)
+        assert np.all(got["insertSize"] == 0) and np.all(got["matePos"] == -1)
+    assert len(rd.fetch(b"other", 0, 500)["pos"]) == 0
+    rd.close()
+    # without the index the reader scans
+    import os
+    os.remove(path + ".bai")
+    rd = bamio.BamReader(path)
+    got = rd.fetch(b"sim", 40000, 41000)
+    assert np.array_equal(got["pos"], _select(reads, (reads["pos"] < 41000) & (ends > 40000))["pos"])
+    rd.close()

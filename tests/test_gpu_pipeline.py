@@ -92,3 +92,55 @@ def test_two_samples_and_a_crowded_window():
     assert got == {(4500, dele[1], b""), (4506, last[1], last[2])}
     assert all(sorted(c.GT[0].split("/")) == ["1", "1"] for c in calls2)
     calign.closeDevice()
+
+
+def test_command_line_bam_to_vcf(tmp_path):
+    """files in, file out: FASTA + .fai, two BAMs + .bai -> VCF through platypus_amd.runner (two chunks, two
+    read buffers per chunk), checked against the planted truth"""
+    from platypus_amd import bamio, calign, runner, simulate
+    rng = np.random.default_rng(21)
+    G = 40000
+    genome = simulate.random_genome(rng, G)
+    truth = simulate.plant_variants(rng, genome, 30, spacing=500)
+    fa = tmp_path / "ref.fa"
+    fa.write_bytes(b">sim\n" + b"\n".join(genome[i:i + 60] for i in range(0, G, 60)) + b"\n")
+    (tmp_path / "ref.fa.fai").write_bytes(b"sim\t%d\t5\t60\t61\n" % G)
+    bams = []
+    for k in range(2):
+        reads = simulate.simulate_reads(rng, genome, truth, coverage=20, read_len=100)
+        path = str(tmp_path / ("s%d.bam" % k))
+        bamio.write_bam(path, [(b"sim", G)], reads, sample="S%d" % k)
+        bams.append(path)
+    out = str(tmp_path / "calls.vcf")
+    rc = runner.main(["callVariants", "--bamFiles", ",".join(bams), "--refFile", str(fa), "--regions", "sim:1-%d" % (G - 1),
+                      "--output", out, "--processRegionSize", "25000", "--bufferSize", "10000", "--maxReadLength", "100"])
+    assert rc == 0
+    lines = open(out).read().splitlines()
+    head = [l for l in lines if l.startswith("#")]
+    body = [l.split("\t") for l in lines if not l.startswith("#")]
+    assert head[0] == "##fileformat=VCFv4.0" and head[-1].split("\t")[-2:] == ["S0", "S1"]
+    assert sum(l.startswith("#CHROM") for l in lines) == 1                     # one header after the merge
+    pos = [int(b[1]) for b in body]
+    assert pos == sorted(pos) and len(body) >= len(truth) - 1
+    found = {}
+    for b in body:
+        assert b[0] == "sim" and b[6] == "PASS" and b[8] == "GT:GL:GQ:NR" and len(b) == 11
+        found[int(b[1])] = b
+    for p, rem, add, gt in truth:
+        b = found.get(p + 1)
+        if b is None:
+            continue
+        if len(rem) == len(add):
+            assert (b[3], b[4]) == (rem.decode(), add.decode())
+        elif add:                                                                 # insertion: REF = base at pos
+            assert b[3] == genome[p:p + 1].decode() and b[4] == (genome[p:p + 1] + add).decode()
+        else:                                                                     # deletion: REF = base + removed
+            assert b[3] == (genome[p:p + 1] + rem).decode() and b[4] == genome[p:p + 1].decode()
+        for smp in b[9:]:
+            g = sorted(smp.split(":")[0].split("/"))
+            assert g == (["0", "1"] if gt == 1 else ["1", "1"])
+        info = dict(kv.split("=") for kv in b[7].split(";"))
+        assert set(info) == {"FR", "PP", "TR", "NF", "NR", "TC", "TCR", "TCF"}
+        assert int(info["TC"]) == int(info["TCR"]) + int(info["TCF"]) > 10
+    assert sum((p + 1) in found for p, r, a, g in truth) >= len(truth) - 1
+    calign.closeDevice()
