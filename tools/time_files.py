@@ -1,0 +1,49 @@
+#!/usr/bin/env python
+"""File-to-file timing: simulated BAM (+ .bai) and FASTA (+ .fai) -> VCF through platypus_amd.runner.
+
+    python tools/time_files.py [genome_kb] [coverage] [workdir]
+"""
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+from platypus_amd import bamio, runner, simulate  # noqa: E402
+
+
+def main():
+    kb = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+    cov = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+    work = sys.argv[3] if len(sys.argv) > 3 else tempfile.mkdtemp(prefix="pa_files_")
+    rng = np.random.default_rng(5)
+    G = kb * 1000
+    t = time.perf_counter()
+    genome = simulate.random_genome(rng, G)
+    truth = simulate.plant_variants(rng, genome, G // 1000, spacing=600)
+    reads = simulate.simulate_reads(rng, genome, truth, coverage=cov, read_len=100)
+    fa = os.path.join(work, "ref.fa")
+    with open(fa, "wb") as f:
+        f.write(b">sim\n" + b"\n".join(genome[i:i + 60] for i in range(0, G, 60)) + b"\n")
+    with open(fa + ".fai", "wb") as f:
+        f.write(b"sim\t%d\t5\t60\t61\n" % G)
+    bam = os.path.join(work, "s.bam")
+    bamio.write_bam(bam, [(b"sim", G)], reads, sample="S")
+    print("simulated and wrote %d kb, %d reads, BAM %.1f MB in %.1f s" % (kb, len(reads["pos"]), os.path.getsize(bam) / 1e6,
+                                                                       time.perf_counter() - t), flush=True)
+    out = os.path.join(work, "calls.vcf")
+    for rep in range(2):
+        t0 = time.perf_counter()
+        runner.main(["callVariants", "--bamFiles", bam, "--refFile", fa, "--regions", "sim:1-%d" % (G - 1), "--output", out,
+                     "--maxReadLength", "100"])
+        dt = time.perf_counter() - t0
+        n = sum(1 for l in open(out) if not l.startswith("#"))
+        print("rep %d: %.2f s -> %.1f Mbp/min, %d VCF records for %d planted variants" % (rep, dt, G / 1e6 / (dt / 60), n,
+                                                                                          len(truth)), flush=True)
+
+
+if __name__ == "__main__":
+    main()
