@@ -16,6 +16,7 @@ path and are not mirrored.
 from libc.stdint cimport int32_t, int64_t, uint8_t
 from libc.stdlib cimport malloc, calloc, free
 from libc.string cimport memcpy
+from libc.math cimport exp
 import time
 
 from platypus_amd.calign cimport deviceContext
@@ -38,6 +39,7 @@ cdef int check(pg_ctx* ctx, int rc) except -1:
 # Results of the genotype / EM kernels stay on the device until the next windows are
 # uploaded; a Population remembers which upload it came from.
 cdef long g_generation = 0
+cdef double mLTOT = -0.23025850929940459
 
 
 cdef class Population:
@@ -296,6 +298,40 @@ cdef class WindowBatch:
                     if rd.isReverse:
                         tcr += 1
         return tc, tcr, tc - tcr
+
+    def siteStatistics(self, int w, int varPos, bytes added, int badReadsWindow):
+        """The read-level counts of Population.vcfINFO for one variant (cpopulation.pyx:274-346) over the
+        window's reads of all individuals: (TC, TCR, TCF, weighted TCR, weighted TCF, minimum base
+        qualities).  The last item lists, for every read that spans varPos and shows the variant's
+        single added base there, the smallest quality in a window of badReadsWindow bases around it
+        (empty unless `added` is one base, cpopulation.pyx:290-310)."""
+        cdef cAlignedRead* rd
+        cdef size_t p
+        cdef int tc = 0, tcr = 0, ws, we, k, mn
+        cdef double wr = 0.0, wf = 0.0
+        cdef list mins = []
+        cdef bint single = len(added) == 1
+        cdef char addedChar = added[0] if single else 0
+        for lst in self.windows[w][3]:
+            for q in lst:
+                p = q
+                rd = <cAlignedRead*>p
+                if rd.pos <= varPos and rd.end >= varPos:
+                    tc += 1
+                    if rd.isReverse:
+                        tcr += 1
+                        wr += 1.0 - exp(mLTOT * rd.mapq)
+                    else:
+                        wf += 1.0 - exp(mLTOT * rd.mapq)
+                    if single and varPos - rd.pos < rd.rlen and rd.seq[varPos - rd.pos] == addedChar:
+                        ws = max(0, varPos - rd.pos - (badReadsWindow - 1) // 2)
+                        we = min(rd.rlen, varPos - rd.pos + (badReadsWindow - 1) // 2)
+                        mn = 100
+                        for k in range(ws, we):
+                            if rd.qual[k] < mn:
+                                mn = rd.qual[k]
+                        mins.append(mn)
+        return tc, tcr, tc - tcr, wr, wf, mins
 
     def readCounts(self, int w):
         """reads per individual of window w"""

@@ -41,6 +41,10 @@ class Options(object):
         self.callOnlyIndels = 0
         self.strandFilter = 0
         self.minPosterior = 5
+        self.sbThreshold = 1e-2
+        self.abThreshold = 1e-3
+        self.badReadsWindow = 11
+        self.badReadsThreshold = 15
         self.maxIters = 100
         for k, v in kw.items():
             if not hasattr(self, k):
@@ -199,11 +203,101 @@ def haplotypesInWindow(window, nReads, refFile, options):
 class Call(object):
     """What outputCallToVCF derives for one output position (variantcaller.pyx:302-436)."""
     __slots__ = ("chrom", "pos", "variants", "posteriors", "PP", "FR", "TR", "NF", "NR", "TC", "TCR", "TCF", "qual",
-                 "GT", "GQ", "GL", "nReads")
+                 "GT", "GQ", "GL", "nReads", "HP", "SC", "RMP", "MMLQ", "FPV", "RPV", "ABPV", "filters")
 
     def __repr__(self):
         return "Call(%s:%d %s PP=%s FR=%s GT=%s)" % (self.chrom.decode(), self.pos, self.variants, self.PP, self.FR,
                                                      self.GT)
+
+
+def _round_half_up(x):
+    """round() of the Python 2 the reference runs on (halves away from zero), for x >= 0"""
+    return int(math.floor(x + 0.5))
+
+
+def logFactorial(x):
+    """cpopulation.pyx:106-121"""
+    if x < 15:
+        return sum(math.log(i) for i in range(1, x + 1))
+    y = float(x)
+    return (y * math.log(y) + math.log(2.0 * math.pi * y) / 2 - y + (y ** -1) / 12 - (y ** -3) / 360 + (y ** -5) / 1260
+            - (y ** -7) / 1680 + (y ** -9) / 1188)
+
+
+def binomial(x, size, prob):
+    """cpopulation.pyx:124-142"""
+    if x == size and prob == 1:
+        return 1.0
+    if x != size and prob == 1:
+        return 0.0
+    if x == 0 and prob == 0:
+        return 1.0
+    if x == 0 and size == 0:
+        return 1.0
+    if prob <= 0.0 or size < x:
+        return 0.0
+    return math.exp(logFactorial(size) - (logFactorial(x) + logFactorial(size - x)) + x * math.log(prob)
+                    + (size - x) * math.log(1.0 - prob))
+
+
+def homopolymerLength(variant, refFile):
+    """chaplotype.pyx:366-402: the longest run touching the variant's position"""
+    left = refFile.getSequence(variant.refName, variant.refPos - 20, variant.refPos)
+    right = refFile.getSequence(variant.refName, variant.refPos + 1, variant.refPos + 21)
+    if len(left) == 0 or len(right) == 0:
+        return 0
+    nl = len(left) - len(left.rstrip(left[-1:]))
+    nr = len(right) - len(right.lstrip(right[:1]))
+    return max(nl, nr) if left[-1:] != right[:1] else nl + nr
+
+
+def siteStatistics(batch, k, variant, freq, refFile, options, minQuals):
+    """INFO statistics of one variant (cpopulation.pyx:239-389, chaplotype.pyx:412-432).  `minQuals` is the
+    window's running list of minimum base qualities: the reference never clears it between the variants
+    of a window (cpopulation.pyx:231,310), so neither is it cleared here."""
+    tc, tcr, tcf, wr, wf, mins = batch.siteStatistics(k, variant.refPos, variant.added, options.badReadsWindow)
+    minQuals.extend(mins)
+    minQuals.sort()
+    med = minQuals[len(minQuals) // 2] if minQuals else 100
+    out = dict(TC=tc, TCR=tcr, TCF=tcf, HP=homopolymerLength(variant, refFile),
+               SC=refFile.getSequence(variant.refName, variant.refPos - 10, variant.refPos + 11),
+               RMP=round(variant.rmsReadPos, 2), MMLQ=med if (variant.nAdded == 1 and variant.nRemoved == 1) else None)
+    nw = variant.nFwdReadsWeighted + variant.nRevReadsWeighted
+    if tc > 0 and nw / float(tc) >= freq / 2.0:                       # cpopulation.pyx:367-373
+        ab = 1.0
+    else:
+        ab = sum(binomial(i, tc, freq / 2.0) for i in range(_round_half_up(nw) + 1))
+    p = min(0.99, freq)
+    fwd = sum(binomial(i, _round_half_up(wf), p) for i in range(_round_half_up(variant.nFwdReadsWeighted) + 1))
+    rev = sum(binomial(i, _round_half_up(wr), p) for i in range(_round_half_up(variant.nRevReadsWeighted) + 1))
+    out.update(FPV="%1.2e" % fwd, RPV="%1.2e" % rev, ABPV="%1.2e" % ab)
+    return out
+
+
+def windowFilters(stats_by_variant, options):
+    """cpopulation.pyx:391-477: the bad-reads, strand-bias and allele-bias flags are raised when ALL variants
+    of the window fail the respective test.  The reference then attaches them to whichever variant its
+    dictionary iteration ended on; here they go to the window's last variant in sorted order."""
+    n = len(stats_by_variant)
+    n_mmlq = n_sb = n_ab = 0
+    for v, st in stats_by_variant:
+        med = st["MMLQ"] if st["MMLQ"] is not None else 100
+        if med < options.badReadsThreshold and not (v.nFwdReads > 0 and v.nRevReads > 0):
+            n_mmlq += 1
+        if v.nFwdReads == 0 and st["TCF"] != 0 and float(st["FPV"]) < options.sbThreshold:
+            n_sb += 1
+        if v.nRevReads == 0 and st["TCR"] != 0 and float(st["RPV"]) < options.sbThreshold:
+            n_sb += 1
+        if float(st["ABPV"]) < options.abThreshold:
+            n_ab += 1
+    flags = []
+    if n and n_mmlq == n:
+        flags.append("badReads")
+    if n and n_sb == n:
+        flags.append("sb")
+    if n and n_ab == n:
+        flags.append("ab")
+    return flags
 
 
 def candidatesInRegion(chrom, start, end, readBuffers, refFile, options):
@@ -309,6 +403,17 @@ def callRegion(chrom, start, end, readBuffers, refFile, options=None, variants=N
         pop = pops[k]
         freqs = pop.frequenciesPy()
         byPos = {}
+        minQuals, stats_list = [], []
+        all_vars = {}
+        for hap in pop.haplotypes:                                    # INFO and FILTER cover every haplotype's variants
+            for v in hap.variantsPy():
+                all_vars[v] = v
+        for v in sorted(all_vars, key=lambda v: v._key()):
+            fr = sum(f for f, hap in zip(freqs, pop.haplotypes) if v in hap.variantsPy())
+            stats_list.append((v, siteStatistics(batch, k, v, fr, refFile, options, minQuals)))
+        win_flags = windowFilters(stats_list, options)
+        stats_of = {v: st for v, st in stats_list}
+        last_var = stats_list[-1][0] if stats_list else None
         for v, p in perWin.get(k, []):
             pp = "%.0f" % (-10.0 * math.log10(max(1e-20, 1.0 - p)))  # cpopulation.pyx:249
             if float(pp) >= options.minPosterior:                     # variantcaller.pyx:304
@@ -324,7 +429,11 @@ def callRegion(chrom, start, end, readBuffers, refFile, options=None, variants=N
             c.TR = [v.nSupportingReads for v in vs]
             c.NF = [v.nFwdReads for v in vs]
             c.NR = [v.nRevReads for v in vs]
-            c.TC, c.TCR, c.TCF = batch.coverage(k, vs[0].refPos)       # of the line's first variant, variantcaller.pyx:329
+            st = stats_of[vs[0]]                                  # lineinfo = info[variants[0]], variantcaller.pyx:329
+            c.TC, c.TCR, c.TCF = st["TC"], st["TCR"], st["TCF"]
+            c.HP, c.SC, c.RMP, c.MMLQ = st["HP"], st["SC"], st["RMP"], st["MMLQ"]
+            c.FPV, c.RPV, c.ABPV = st["FPV"], st["RPV"], st["ABPV"]
+            c.filters = sorted(set(win_flags)) if any(v == last_var for v in vs) else []
             c.qual = max(int(pp) for pp in c.PP)
             c.GT, c.GQ, c.GL, c.nReads = [], [], [], []
             for ind, g in enumerate(pop.genotypeCalls):

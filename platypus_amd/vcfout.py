@@ -1,8 +1,7 @@
 """VCF text for the calls of platypus_amd.pipeline: the line layout of the reference's writer
 (platypus/vcf.py:710-739 with the field order of format_formatdata, :297-328), REF/ALT by
-the rule of platypus/variantcaller.pyx:442-502.  INFO carries the fields this package computes
-(FR, PP, TR, NF, NR, TC, TCR, TCF); the reference's strand/allele-bias statistics and their
-filters (cpopulation.pyx:362-474) are not computed, so FILTER is always PASS."""
+the rule of platypus/variantcaller.pyx:442-502, INFO / FILTER / FORMAT fields of
+platypus/cpopulation.pyx:46-79."""
 import datetime
 
 INFO = [("FR", ".", "Float", "Estimated population frequency"),
@@ -12,7 +11,17 @@ INFO = [("FR", ".", "Float", "Estimated population frequency"),
         ("TCF", "1", "Integer", "Total forward strand coverage at this locus"),
         ("TR", ".", "Integer", "Total number of reads containing this variant"),
         ("NF", ".", "Integer", "Total number of forward reads containing this variant"),
-        ("NR", ".", "Integer", "Total number of reverse reads containing this variant")]
+        ("NR", ".", "Integer", "Total number of reverse reads containing this variant"),
+        ("SC", "1", "String", "Genomic sequence 10 bases either side of variant position"),
+        ("RMP", ".", "Float", "RMS Position in reads of Variant"),
+        ("HP", "1", "Integer", "Homopolmer run length"),
+        ("FPV", ".", "Float", "Forward strand p-value"),
+        ("RPV", ".", "Float", "Reverse strand p-value"),
+        ("ABPV", ".", "Float", "Allele-bias p-value. Testing for low variant coverage"),
+        ("MMLQ", ".", "Float", "Median minimum base quality for bases around variant")]
+FILTER = [("ab", "Variant fails allele-bias filter"), ("sb", "Variant fails strand-bias filter"),
+          ("badReads", "Variant supported only by reads with low quality bases close to variant position, and not present "
+                       "on both strands.")]
 FORMAT = [("GT", "1", "String", "Unphased genotypes"),
           ("GL", ".", "Float", "Genotype log-likelihoods (log10) for AA,AB and BB genotypes, where A = ref and B = variant. "
                                "Only applicable for bi-allelic sites"),
@@ -27,6 +36,8 @@ def header(samples, options_text=""):
         lines.append("##platypusOptions=%s" % options_text)
     for k, n, t, d in INFO:
         lines.append('##INFO=<ID=%s,Number=%s,Type=%s,Description="%s">' % (k, n, t, d))
+    for k, d in FILTER:
+        lines.append('##FILTER=<ID=%s,Description="%s">' % (k, d))
     for k, n, t, d in FORMAT:
         lines.append('##FORMAT=<ID=%s,Number=%s,Type=%s,Description="%s">' % (k, n, t, d))
     lines.append("\t".join(["#CHROM", "POS", "ID", "REF", "ALT", "QUAL", "FILTER", "INFO", "FORMAT"] + list(samples)))
@@ -59,10 +70,13 @@ def _num(x):
 
 def record(call, refFile):
     ref, alts = ref_and_alt(call.chrom, call.pos, call.variants, refFile)
-    info = dict(FR=call.FR, PP=call.PP, TR=call.TR, NF=call.NF, NR=call.NR, TC=[call.TC], TCR=[call.TCR], TCF=[call.TCF])
+    info = dict(FR=call.FR, PP=call.PP, TR=call.TR, NF=call.NF, NR=call.NR, TC=[call.TC], TCR=[call.TCR], TCF=[call.TCF],
+                HP=[call.HP], SC=[call.SC.decode()], RMP=[call.RMP], FPV=[call.FPV], RPV=[call.RPV], ABPV=[call.ABPV])
+    if call.MMLQ is not None:
+        info["MMLQ"] = [call.MMLQ]
     info_text = ";".join("%s=%s" % (k, ",".join(str(x) for x in info[k])) for k in sorted(info))
     cols = [call.chrom.decode(), str(call.pos + 1), ".", ref.decode(), ",".join(a.decode() for a in alts),
-            str(call.qual), "PASS", info_text, "GT:GL:GQ:NR"]
+            str(call.qual), ";".join(call.filters) if call.filters else "PASS", info_text, "GT:GL:GQ:NR"]
     for i in range(len(call.GT)):
         cols.append("%s:%s:%s:%s" % (call.GT[i], ",".join(str(x) for x in call.GL[i]),
                                      "." if call.GQ[i] == -1 else call.GQ[i], call.nReads[i]))

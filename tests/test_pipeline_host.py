@@ -175,3 +175,19 @@ def test_simulator_alignments_are_consistent():
     # error-free reads: every candidate is a planted variant, and every planted variant with coverage is found
     assert found <= {(p, r, a) for p, r, a, g in variants}
     assert len(found) >= len(variants) - 1
+
+
+def test_binomial_statistics():
+    """cpopulation.pyx:106-142 against exact values"""
+    import math
+    for n, k, p in [(10, 3, 0.5), (30, 0, 0.1), (14, 14, 0.9), (40, 7, 0.25)]:
+        exact = math.comb(n, k) * p ** k * (1 - p) ** (n - k)
+        assert abs(pipeline.binomial(k, n, p) - exact) < 2e-4 * exact + 1e-300      # Stirling series above 14
+    assert pipeline.binomial(5, 5, 1) == 1.0 and pipeline.binomial(4, 5, 1) == 0.0 and pipeline.binomial(0, 7, 0) == 1.0
+    assert abs(pipeline.logFactorial(10) - math.lgamma(11)) < 1e-12 and abs(pipeline.logFactorial(50) - math.lgamma(51)) < 1e-9
+    ref = b"ACGTTTTTTGCAAAAAAGGCTTAACCGGATATCGCGATTACAGGCTAGCTAGGATCC" * 3
+    fa = FastaFile(sequences={b"c": ref})
+    t0 = ref.index(b"GTTTTTTG") + 1
+    assert pipeline.homopolymerLength(Variant(b"c", t0 - 1, b"", b"T"), fa) == 6            # G | TTTTTT
+    assert pipeline.homopolymerLength(Variant(b"c", t0 + 2, b"T", b"A"), fa) == 5           # TT [T] TTT: 2 + 3
+    assert pipeline.homopolymerLength(Variant(b"c", 100, b"A", b"C"), fa) >= 1
