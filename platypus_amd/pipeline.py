@@ -364,7 +364,11 @@ def callRegion(chrom, start, end, readBuffers, refFile, options=None, variants=N
         if nReads[i] == 0:
             continue
         seen, haps = set(), []
-        for h in [refHap[i]] + haplotypesInWindow(w, nReads[i], refFile, options):
+        try:                                                          # a window that cannot be built is skipped,
+            varHaps = haplotypesInWindow(w, nReads[i], refFile, options)   # as the reference does (variantcaller.pyx:189-191)
+        except Exception:
+            continue
+        for h in [refHap[i]] + varHaps:
             key = (h.startPosPy, h.sequence)                          # list(set(...)) of variantcaller.pyx:170
             if key not in seen:
                 seen.add(key)
