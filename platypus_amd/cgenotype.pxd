@@ -1,18 +1,14 @@
-from platypus_amd.chaplotype cimport Haplotype
+# Declarations of the genotype layer; attribute and method names follow platypus/cgenotype.pxd:5-20
+# so that code written against the reference compiles against this module.
 from platypus_amd.samtoolsWrapper cimport cAlignedRead
-
-# platypus/cgenotype.pxd:5-17
-cdef class DiploidGenotype:
-    cdef public list haplotypes
-    cdef Haplotype hap1
-    cdef Haplotype hap2
-    cdef double calculateDataLikelihood(
-            DiploidGenotype self,
-            cAlignedRead** start,
-            cAlignedRead** end,
-            int individualIndex,
-            int nReads,
-            int nIndividuals
-    ) except? -1.0
+from platypus_amd.chaplotype cimport Haplotype
 
 cdef list generateAllGenotypesFromHaplotypeList(int ploidy, list haplotypes)
+
+
+cdef class DiploidGenotype:
+    cdef Haplotype hap1, hap2
+    cdef public list haplotypes      # [hap1, hap2]
+    # sum over the reads [start, end) of log(0.5 (L1 + L2)), computed on the device
+    cdef double calculateDataLikelihood(DiploidGenotype self, cAlignedRead** start, cAlignedRead** end,
+                                        int individualIndex, int nReads, int nIndividuals) except? -1.0

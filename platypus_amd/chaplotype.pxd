@@ -1,28 +1,21 @@
+# Declarations of the haplotype layer.  Attribute and method names are those of the part of
+# platypus/chaplotype.pxd:7-34 that the alignment path touches.
 from platypus_amd.samtoolsWrapper cimport cAlignedRead
 
-# the attributes and the method of the reference's Haplotype that the
-# alignment path touches, platypus/chaplotype.pxd:7-34
-cdef class Haplotype:
-    cdef bytes refName
-    cdef int startPos
-    cdef int endPos
-    cdef tuple variants
-    cdef bytes haplotypeSequence
-    cdef char* cHaplotypeSequence
-    cdef double** likesByIndCache
-    cdef int lenCache
-    cdef int hash
-    cdef int hapLen
-    cdef int varSeqLen
-    cdef char* cHomopolQ
-    cdef int ensureCache(self, int nIndividuals) except -1
-    cdef double* alignReads(
-            self,
-            int individualIndex,
-            cAlignedRead** start,
-            cAlignedRead** end,
-            int nReads,
-            int nIndividuals
-    ) except NULL
-
 cdef int prefetchWindowC(list haplotypes, list readBuffers, bint always=*) except -1
+
+
+cdef class Haplotype:
+    # where and what
+    cdef bytes refName, haplotypeSequence
+    cdef int startPos, endPos, hapLen, varSeqLen, hash
+    cdef tuple variants
+    # what the aligner is fed from
+    cdef char* cHaplotypeSequence
+    cdef char* cHomopolQ
+    # likelihoods per individual, filled by the device
+    cdef int lenCache
+    cdef double** likesByIndCache
+    cdef int ensureCache(self, int nIndividuals) except -1
+    cdef double* alignReads(self, int individualIndex, cAlignedRead** start, cAlignedRead** end, int nReads,
+                            int nIndividuals) except NULL

@@ -1,37 +1,29 @@
-# the numeric part of platypus/cpopulation.pxd:4-47 (VCF formatting is not on the path)
+# Declarations of the caller layer.  Names follow the numeric part of platypus/cpopulation.pxd:4-47;
+# the VCF-formatting members of the reference's Population live in platypus_amd/pipeline.py.
+
 cdef class Population:
-    cdef public list genotypeCalls
-    cdef public list genotypeLikelihoods
-    cdef public list haplotypes
-    cdef double** genotypePosteriors
-    cdef double* frequencies
-    cdef int** haplotypeIndexes
-    cdef int* nReads
-    cdef int nHaplotypes
-    cdef int nIndividuals
-    cdef int nGenotypes
-    cdef int verbosity
+    # results of one window, copied from the device
+    cdef double* frequencies                       # per haplotype
+    cdef double** genotypePosteriors               # [individual][genotype]
+    cdef int** haplotypeIndexes                    # [genotype] -> two haplotype indexes
+    cdef int* nReads                               # per individual
+    cdef int nHaplotypes, nIndividuals, nGenotypes, verbosity
+    cdef public list genotypeCalls, genotypeLikelihoods, haplotypes
     cdef list readBuffers
-    cdef public int nIterations
+    # bookkeeping of this implementation
+    cdef public int nIterations, windowIndex
     cdef public double maxChange
-    cdef public int windowIndex
     cdef long generation
     cdef double calculatePosterior(self, object var) except? -1.0
 
 
 cdef class Caller:
-    cdef int nHaplotypes
-    cdef int nIndividuals
-    cdef int nGenotypes
-    cdef int ploidy
-    cdef int verbosity
-    cdef list haplotypes
-    cdef list genotypes
-    cdef list readBuffers
+    cdef int nHaplotypes, nIndividuals, nGenotypes, ploidy, verbosity
     cdef int* nReads
+    cdef list haplotypes, genotypes, readBuffers
     cdef object options
-    cdef Population call(self, int maxIters=*)
     cdef setup(self, list haplotypes, list genotypes, int nInd, int ploidy, int verbosity, list readBuffers)
+    cdef Population call(self, int maxIters=*)
 
 
 # collect -> run -> consume over many windows (the rework of the window loop of

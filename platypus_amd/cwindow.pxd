@@ -1,19 +1,17 @@
+# Declarations of the read buffer.  Attribute names are those of platypus/cwindow.pxd:5-16.
 from platypus_amd.samtoolsWrapper cimport cAlignedRead
 
-# same attribute block as the reference, platypus/cwindow.pxd:5-16
+cdef int bisectReadsLeft(cAlignedRead** reads, int testPos, int nReads)
+
+
 cdef class bamReadBuffer:
     cdef bytes chromBytes
     cdef char* chrom
-    cdef int startBase
-    cdef int endBase
-    cdef int nReads
-    cdef int longestRead
-    cdef cAlignedRead** cReads
-    cdef cAlignedRead** start
-    cdef cAlignedRead** end
-    cdef cAlignedRead** windowStart
+    cdef int startBase, endBase, nReads, longestRead
+    cdef cAlignedRead** cReads                      # all buffered reads, sorted by position
+    cdef cAlignedRead** start                       # == cReads
+    cdef cAlignedRead** end                         # one past the last read
+    cdef cAlignedRead** windowStart                 # the current window's reads: [windowStart, windowEnd)
     cdef cAlignedRead** windowEnd
     cdef object keepAlive
     cdef setWindowPointers(self, int start, int end)
-
-cdef int bisectReadsLeft(cAlignedRead** reads, int testPos, int nReads)
