@@ -68,6 +68,46 @@ def pmc_traffic(n_pairs, read_len):
     return (2.0 * val["FETCH_SIZE"] + val["WRITE_SIZE"]) * 1024.0, os.path.relpath(files[-1], ROOT)
 
 
+def end_to_end_leg(kb=1000, coverage=30):
+    """Simulate kb kilobases at the given coverage (one planted variant per kb, 100-bp reads with true CIGARs),
+    write BAM + .bai and FASTA + .fai, call them to a VCF with platypus_amd.runner, time the call."""
+    import shutil
+    import tempfile
+    from platypus_amd import bamio, runner, simulate
+    rng = np.random.default_rng(5)
+    G = kb * 1000
+    work = tempfile.mkdtemp(prefix="platypus_amd_bench_")
+    try:
+        genome = simulate.random_genome(rng, G)
+        truth = simulate.plant_variants(rng, genome, G // 1000, spacing=600)
+        reads = simulate.simulate_reads(rng, genome, truth, coverage=coverage, read_len=100)
+        fa = os.path.join(work, "ref.fa")
+        with open(fa, "wb") as f:
+            f.write(b">sim\n" + b"\n".join(genome[i:i + 60] for i in range(0, G, 60)) + b"\n")
+        with open(fa + ".fai", "wb") as f:
+            f.write(b"sim\t%d\t5\t60\t61\n" % G)
+        bam = os.path.join(work, "s.bam")
+        bamio.write_bam(bam, [(b"sim", G)], reads, sample="S")
+        out = os.path.join(work, "calls.vcf")
+        best = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            runner.main(["callVariants", "--bamFiles", bam, "--refFile", fa, "--regions", "sim:1-%d" % (G - 1),
+                         "--output", out, "--maxReadLength", "100"])
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        called = set()
+        for line in open(out):
+            if not line.startswith("#"):
+                called.add(int(line.split("\t")[1]) - 1)
+        return {"mbp_per_min": G / 1e6 / (best / 60.0), "seconds": best, "genome_kb": kb, "coverage": coverage,
+                "reads": int(len(reads["pos"])), "bam_mb": os.path.getsize(bam) / 1e6, "vcf_records": len(called),
+                "planted_variants": len(truth), "planted_found": sum(p in called for p, r, a, g in truth),
+                "processes": 1, "what": "simulated BAM + .bai and FASTA + .fai -> VCF, platypus_amd.runner"}
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -76,6 +116,7 @@ def main():
     ap.add_argument("--windows", type=int, default=32768, help="windows per GPU (128 pairs each)")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the file-to-file end-to-end leg")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="wgs",
                     help="pair stream to synthesise; wgs is the configuration the metric is quoted on")
     args = ap.parse_args()
@@ -192,6 +233,15 @@ def main():
     except native.PlatGpuError as e:                       # reported, never hidden
         caller = {"error": str(e)}
 
+    # ---- file to file (simulated BAM + FASTA -> VCF through the region caller), not part of the metric:
+    # the second figure BASELINE.json names, Mbp/min, for ONE process / one GPU -------------------------
+    e2e = None
+    if not args.no_e2e and args.workload == "wgs":
+        try:
+            e2e = end_to_end_leg()
+        except Exception as e:                             # reported, never hidden
+            e2e = {"error": "%s: %s" % (type(e).__name__, e)}
+
     # ---- CPU baseline: the reference's own compiled routine on the host cores ---------
     cpu = None
     if not args.no_cpu:
@@ -228,6 +278,7 @@ def main():
         "roofline": roofline,
         "cpu_baseline": cpu,
         "caller_stage": caller,
+        "end_to_end": e2e,
     }
     print(json.dumps(out), flush=True)
     ctx.close()
