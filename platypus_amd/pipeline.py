@@ -107,7 +107,8 @@ def filterVariants(varList, refFile, maxReadLength, minSupport, strandFilter, ma
         return True
 
     for v in varList:
-        new = convertVariantToStandardFormat(v, refFile, maxReadLength)
+        # SNPs and equal-length substitutions are their own standard form (chaplotype.pyx:546-547)
+        new = v if v.nAdded == v.nRemoved else convertVariantToStandardFormat(v, refFile, maxReadLength)
         if last is None:
             last = new
         elif new == last:
@@ -215,8 +216,18 @@ def _round_half_up(x):
     return int(math.floor(x + 0.5))
 
 
+_LOG_FACT = {}
+
+
 def logFactorial(x):
-    """cpopulation.pyx:106-121"""
+    """cpopulation.pyx:106-121 (values are memoised)"""
+    v = _LOG_FACT.get(x)
+    if v is None:
+        v = _LOG_FACT[x] = _logFactorial(x)
+    return v
+
+
+def _logFactorial(x):
     if x < 15:
         return sum(math.log(i) for i in range(1, x + 1))
     y = float(x)
