@@ -70,7 +70,8 @@ def _copy(genome, variants, which):
     return b"".join(seq), segs
 
 
-def simulate_reads(rng, genome, variants, coverage=30, read_len=100, error_rate=0.005, chrom=b"sim"):
+def simulate_reads(rng, genome, variants, coverage=30, read_len=100, error_rate=0.005, chrom=b"sim",
+                   error_qual=(5, 25)):
     """dict of packed record arrays, sorted by position"""
     copies = [_copy(genome, variants, w) for w in (0, 1)]
     starts = [np.array([sg[1] for sg in segs]) for _, segs in copies]     # haplotype start of every segment
@@ -119,7 +120,7 @@ def simulate_reads(rng, genome, variants, coverage=30, read_len=100, error_rate=
         q = rng.integers(25, 41, read_len).astype(np.uint8)
         err = rng.random(read_len) < error_rate
         s[err] = ACGT[rng.integers(0, 4, int(err.sum()))]
-        q[err] = rng.integers(5, 25, int(err.sum()))
+        q[err] = rng.integers(error_qual[0], error_qual[1], int(err.sum()))
         flag = 0x10 if rng.random() < 0.5 else 0
         recs.append((pos, s, q, flag, merged))
     recs.sort(key=lambda r: r[0])

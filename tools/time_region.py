@@ -25,7 +25,10 @@ def main():
     t = time.perf_counter()
     genome = simulate.random_genome(rng, G)
     truth = simulate.plant_variants(rng, genome, G // 1000, spacing=600)
-    reads = [simulate.simulate_reads(rng, genome, truth, coverage=cov, read_len=100) for _ in range(n_samples)]
+    err = float(os.environ.get("TR_ERROR_RATE", "0.005"))        # substitution errors per base
+    reads = [simulate.simulate_reads(rng, genome, truth, coverage=cov, read_len=100, error_rate=err,
+                                     error_qual=(5, int(os.environ.get("TR_ERROR_QMAX", "25"))))
+             for _ in range(n_samples)]
     print("simulated %d kb, %d variants, %d x %d reads in %.1f s" % (kb, len(truth), n_samples, len(reads[0]["pos"]),
                                                                       time.perf_counter() - t), flush=True)
     fa = FastaFile(sequences={b"sim": genome})
