@@ -223,3 +223,36 @@ def test_standalone_hash_sequence_and_map_read():
             ctx.map_read(b"ACGTACGTACGT", 100, bad)
     finally:
         ctx.close()
+
+
+def test_longest_haplotypes_and_mixed_lengths(ctx):
+    """Indel-bearing haplotypes at the upper length limit (16383, calign.pyx:112) beside short ones in one
+    batch: the vote kernel's counters need the most LDS there; reads of 20..250 bases; 300 reads per haplotype."""
+    from platypus_amd import synth
+    rng = np.random.default_rng(77)
+    A = np.frombuffer(b"ACGT", np.uint8)
+    lens = [16383, 15000, 600, 16383, 90]
+    haps = [A[rng.integers(0, 4, n)] for n in lens]
+    haps[3][5000:5400] = A[0]                                   # a long homopolymer: many repeated 7-mers
+    reads, quals, pos, ph, pr = [], [], [], [], []
+    for h, hp in enumerate(haps):
+        for _ in range(300):
+            rl = int(rng.integers(20, 251))
+            rl = min(rl, len(hp) - 20)
+            o = int(rng.integers(0, len(hp) - rl))
+            s = hp[o:o + rl].copy()
+            if rl > 60 and rng.random() < 0.5:                   # an indel relative to the haplotype
+                cut = int(rng.integers(20, rl - 20))
+                s = np.concatenate([s[:cut], s[cut + int(rng.integers(1, 6)):]]) if rng.random() < 0.5 else \
+                    np.concatenate([s[:cut], A[rng.integers(0, 4, int(rng.integers(1, 6)))], s[cut:]])
+            sub = rng.random(len(s)) < 0.02
+            s[sub] = A[rng.integers(0, 4, int(sub.sum()))]
+            reads.append(s); quals.append(rng.integers(2, 42, len(s)).astype(np.uint8)); pos.append(100 + o)
+            ph.append(h); pr.append(len(reads) - 1)
+    b = dict(hap_seq=np.concatenate(haps), hap_off=np.concatenate([[0], np.cumsum(lens)]).astype(np.int64),
+             hap_start=np.full(len(haps), 100, np.int32), hap_varlen=np.array([2, 1, 3, 4, 1], np.int32),
+             read_seq=np.concatenate(reads), read_qual=np.concatenate(quals),
+             read_off=np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.int64),
+             read_pos=np.array(pos, np.int32), read_mapq=np.full(len(reads), 40, np.int32),
+             pair_hap=np.array(ph, np.int32), pair_read=np.array(pr, np.int32))
+    _check_batch(ctx, b)
