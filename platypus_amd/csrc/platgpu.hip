@@ -782,12 +782,12 @@ int pg_caller_launch(pg_ctx* c, int max_iters) {
     if (c->max_win_full <= 4096) { stage = (int)c->max_win_full; lds += (size_t)stage * sizeof(double); }
     PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_em), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_CALLER_EM], c->stream));
-    // Kernel choice: windows of at most 8 haplotypes take one wavefront each; few large windows with
-    // several individuals run one launch pair per iteration over (window, individuals) so that the
+    // Kernel choice: windows of at most 8 haplotypes take one wavefront each; few large windows (more than
+    // 64 haplotypes, at most 256 windows) with several individuals run one launch pair per iteration over (window, individuals) so that the
     // whole chip works on them; everything else takes one workgroup per window.
     // PG_EM_KERNEL = small | big | multi forces one of them (experiments, tests).
     const char* force = std::getenv("PG_EM_KERNEL");
-    int path = n_max <= 8 ? 0 : (c->n_windows <= 256 && c->max_win_inds >= 4 ? 2 : 1);
+    int path = n_max <= 8 ? 0 : (n_max > 64 && c->n_windows <= 256 && c->max_win_inds >= 4 ? 2 : 1);
     if (force && force[0] == 'b') path = 1;
     if (force && force[0] == 'm') path = 2;
     if (force && force[0] == 's' && n_max <= 8) path = 0;
