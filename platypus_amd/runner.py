@@ -6,8 +6,8 @@
 The scheduling is the reference's (platypus/runner.py:98-165): regions are cut into chunks of
 --processRegionSize, every chunk is called on its own into a temporary file and the files are
 concatenated in (chromosome, start) order.  Where the reference deals chunks to --nCPU worker
-processes, here they are dealt to --nGPU processes, each bound to one device; nothing is
-exchanged between them.  Inside a chunk reads are buffered --bufferSize bases at a time
+processes, here they are dealt to --nGPU x --workersPerGPU processes, each bound to one device;
+nothing is exchanged between them.  Inside a chunk reads are buffered --bufferSize bases at a time
 (platypus/variantcaller.pyx:229-233)."""
 import argparse
 import multiprocessing
@@ -65,7 +65,7 @@ def call_chunk(chunk, args, out_path):
 
 
 def _worker(rank, chunks, args, tmpdir, queue):
-    os.environ["PLATGPU_DEVICE"] = str(rank)
+    os.environ["PLATGPU_DEVICE"] = str(rank % max(1, args.nGPU))     # workers of one GPU share its device
     total = 0
     for ch in chunks:
         total += call_chunk(ch, args, os.path.join(tmpdir, "output_temp_" + shard.region_name(ch)))
@@ -80,6 +80,9 @@ def main(argv=None):
     ap.add_argument("--regions", default=None)
     ap.add_argument("--output", "-o", default="AllVariants.vcf")
     ap.add_argument("--nGPU", type=int, default=1)
+    ap.add_argument("--workersPerGPU", type=int, default=1,
+                    help="host processes per device: the host side (BAM decoding, candidates, windows) dominates the "
+                         "run time, so several processes can share one GPU")
     ap.add_argument("--processRegionSize", type=int, default=1000000)
     ap.add_argument("--bufferSize", type=int, default=1000000)
     from platypus_amd import pipeline
@@ -90,14 +93,15 @@ def main(argv=None):
     fa = FastaFile(args.refFile, args.refFile + ".fai")
     chunks = shard.split_regions(parse_regions(args.regions, fa), args.processRegionSize)
     tmpdir = tempfile.mkdtemp(prefix="platypus_amd_")
-    per_rank = shard.assign(chunks, max(1, args.nGPU))
-    if args.nGPU <= 1:
+    n_workers = max(1, args.nGPU) * max(1, args.workersPerGPU)
+    per_rank = shard.assign(chunks, n_workers)
+    if n_workers <= 1:
         for ch in chunks:
             call_chunk(ch, args, os.path.join(tmpdir, "output_temp_" + shard.region_name(ch)))
     else:
         ctx = multiprocessing.get_context("spawn")      # a fresh process per device: nothing of the parent's GPU state
         queue = ctx.Queue()
-        procs = [ctx.Process(target=_worker, args=(r, per_rank[r], args, tmpdir, queue)) for r in range(args.nGPU)]
+        procs = [ctx.Process(target=_worker, args=(r, per_rank[r], args, tmpdir, queue)) for r in range(n_workers)]
         for p in procs:
             p.start()
         for p in procs:

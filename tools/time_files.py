@@ -35,10 +35,11 @@ def main():
     print("simulated and wrote %d kb, %d reads, BAM %.1f MB in %.1f s" % (kb, len(reads["pos"]), os.path.getsize(bam) / 1e6,
                                                                        time.perf_counter() - t), flush=True)
     out = os.path.join(work, "calls.vcf")
+    extra = os.environ.get("TF_ARGS", "").split()               # e.g. "--workersPerGPU 4 --processRegionSize 500000"
     for rep in range(2):
         t0 = time.perf_counter()
         runner.main(["callVariants", "--bamFiles", bam, "--refFile", fa, "--regions", "sim:1-%d" % (G - 1), "--output", out,
-                     "--maxReadLength", "100"])
+                     "--maxReadLength", "100"] + extra)
         dt = time.perf_counter() - t0
         n = sum(1 for l in open(out) if not l.startswith("#"))
         print("rep %d: %.2f s -> %.1f Mbp/min, %d VCF records for %d planted variants" % (rep, dt, G / 1e6 / (dt / 60), n,
