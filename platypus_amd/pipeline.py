@@ -66,30 +66,39 @@ def convertVariantToStandardFormat(variant, refFile, maxReadLength):
     ref = refFile.getSequence(variant.refName, windowMin, windowMax)
     hap = chaplotype.Haplotype.fromVariants(variant.refName, windowMin, windowMax, (variant,), refFile, 0).sequence
     lenRef, lenHap = len(ref), len(hap)
-    for index in range(min(lenRef, lenHap)):
-        if hap[lenHap - index - 1] != ref[lenRef - index - 1]:
-            newAdded, newRemoved, newPos = b"", b"", -1
-            if nAdded > 0:
-                newPos = windowMin + (lenRef - 1) - index
-                insStart = newPos - windowMin + 1
-                newAdded = hap[insStart:insStart + nAdded]
-            if nRemoved > 0:
-                newPos = windowMin + (lenRef - 1) - index - nRemoved
-                delStart = newPos - windowMin + 1
-                newRemoved = ref[delStart:delStart + nRemoved]
-            effectSize = len(newRemoved) + len(newAdded) + abs(newPos - variant.refPos)
-            newVar = Variant(variant.refName, newPos, newRemoved, newAdded, variant.nSupportingReads,
-                             variant.nFwdReads, 0, 0, 0)
-            newVar.maxPos = newPos + effectSize
-            newVar.minPos = newPos
-            newVar.sumSqReadPos = variant.sumSqReadPos
-            newVar.rmsReadPos = variant.rmsReadPos
-            newVar.nFwdReadsWeighted = variant.nFwdReadsWeighted
-            newVar.nRevReadsWeighted = variant.nRevReadsWeighted
-            if len(newAdded) != nAdded or len(newRemoved) != nRemoved:
-                raise ValueError("Error in variant conversion to standard format: %s" % variant)
-            return newVar
-    raise ValueError("Error in variant conversion to standard format. Variant = %s" % variant)
+    # the first mismatch from the right = the length of the longest common suffix; 'a suffix of
+    # length k matches' is monotone in k, so it is found by bisection over slice comparisons
+    lo, hi = 0, min(lenRef, lenHap)
+    while lo < hi:
+        mid = (lo + hi + 1) >> 1
+        if hap[lenHap - mid:] == ref[lenRef - mid:]:
+            lo = mid
+        else:
+            hi = mid - 1
+    index = lo
+    if index >= min(lenRef, lenHap):
+        raise ValueError("Error in variant conversion to standard format. Variant = %s" % variant)
+    newAdded, newRemoved, newPos = b"", b"", -1
+    if nAdded > 0:
+        newPos = windowMin + (lenRef - 1) - index
+        insStart = newPos - windowMin + 1
+        newAdded = hap[insStart:insStart + nAdded]
+    if nRemoved > 0:
+        newPos = windowMin + (lenRef - 1) - index - nRemoved
+        delStart = newPos - windowMin + 1
+        newRemoved = ref[delStart:delStart + nRemoved]
+    effectSize = len(newRemoved) + len(newAdded) + abs(newPos - variant.refPos)
+    newVar = Variant(variant.refName, newPos, newRemoved, newAdded, variant.nSupportingReads,
+                     variant.nFwdReads, 0, 0, 0)
+    newVar.maxPos = newPos + effectSize
+    newVar.minPos = newPos
+    newVar.sumSqReadPos = variant.sumSqReadPos
+    newVar.rmsReadPos = variant.rmsReadPos
+    newVar.nFwdReadsWeighted = variant.nFwdReadsWeighted
+    newVar.nRevReadsWeighted = variant.nRevReadsWeighted
+    if len(newAdded) != nAdded or len(newRemoved) != nRemoved:
+        raise ValueError("Error in variant conversion to standard format: %s" % variant)
+    return newVar
 
 
 def filterVariants(varList, refFile, maxReadLength, minSupport, strandFilter, maxDiff):

@@ -35,22 +35,43 @@ def parse_regions(text, fasta):
     return out
 
 
-def call_chunk(chunk, args, out_path):
+def call_chunks(chunks, args, tmpdir):
+    """Calls every chunk of the list into its own temporary file.  The reads of the next buffer are
+    fetched (file reads and BGZF inflation, both outside the interpreter lock) on a helper thread
+    while the current buffer is being called."""
+    from concurrent.futures import ThreadPoolExecutor
     from platypus_amd import bamio, pipeline, simulate, vcfout
     from platypus_amd.fastafile import FastaFile
-    chrom, start, end = chunk
     fa = FastaFile(args.refFile, args.refFile + ".fai")
     readers = [bamio.BamReader(b) for b in args.bamFiles.split(",")]
     samples = [r.sample or os.path.basename(r.fileName) for r in readers]
     opts = pipeline.Options(**{k: getattr(args, k) for k in vars(pipeline.Options()) if hasattr(args, k)})
-    n_calls = 0
-    with open(out_path, "w") as out:
-        out.write("\n".join(vcfout.header(samples, " ".join(sys.argv[1:]))) + "\n")
-        for s in range(start, end, args.bufferSize):
-            e = min(s + args.bufferSize, end)
+    units = [(ch, s, min(s + args.bufferSize, ch[2])) for ch in chunks for s in range(ch[1], ch[2], args.bufferSize)]
+
+    def load(unit):
+        (chrom, _, _), s, e = unit
+        return [r.fetch(chrom, s, e) for r in readers]
+
+    header = "\n".join(vcfout.header(samples, " ".join(sys.argv[1:]))) + "\n"
+    for ch in chunks:
+        if ch[1] >= ch[2]:                                                # an empty chunk still has its (header only) file
+            with open(os.path.join(tmpdir, "output_temp_" + shard.region_name(ch)), "w") as f:
+                f.write(header)
+    n_calls, out, current = 0, None, None
+    with ThreadPoolExecutor(1) as pool:
+        pending = pool.submit(load, units[0]) if units else None
+        for i, (ch, s, e) in enumerate(units):
+            fetched = pending.result()
+            pending = pool.submit(load, units[i + 1]) if i + 1 < len(units) else None
+            if ch is not current:
+                if out is not None:
+                    out.close()
+                out = open(os.path.join(tmpdir, "output_temp_" + shard.region_name(ch)), "w")
+                out.write(header)
+                current = ch
+            chrom = ch[0]
             bufs = []
-            for r in readers:
-                reads = r.fetch(chrom, s, e)
+            for reads in fetched:
                 reads["chrom"] = chrom.encode()
                 bufs.append(simulate.buffer_of(reads, s, e, minMapQual=opts.minMapQual, maxReads=int(opts.maxReads),
                                                minGoodQualBases=opts.minGoodQualBases, maxBadQualBases=opts.maxBadQualBases))
@@ -59,6 +80,8 @@ def call_chunk(chunk, args, out_path):
             for c in pipeline.callRegion(chrom.encode(), s, e, bufs, fa, opts):
                 out.write(vcfout.record(c, fa) + "\n")
                 n_calls += 1
+    if out is not None:
+        out.close()
     for r in readers:
         r.close()
     return n_calls
@@ -66,10 +89,7 @@ def call_chunk(chunk, args, out_path):
 
 def _worker(rank, chunks, args, tmpdir, queue):
     os.environ["PLATGPU_DEVICE"] = str(rank % max(1, args.nGPU))     # workers of one GPU share its device
-    total = 0
-    for ch in chunks:
-        total += call_chunk(ch, args, os.path.join(tmpdir, "output_temp_" + shard.region_name(ch)))
-    queue.put((rank, total))
+    queue.put((rank, call_chunks(chunks, args, tmpdir)))
 
 
 def main(argv=None):
@@ -96,8 +116,7 @@ def main(argv=None):
     n_workers = max(1, args.nGPU) * max(1, args.workersPerGPU)
     per_rank = shard.assign(chunks, n_workers)
     if n_workers <= 1:
-        for ch in chunks:
-            call_chunk(ch, args, os.path.join(tmpdir, "output_temp_" + shard.region_name(ch)))
+        call_chunks(chunks, args, tmpdir)
     else:
         ctx = multiprocessing.get_context("spawn")      # a fresh process per device: nothing of the parent's GPU state
         queue = ctx.Queue()
