@@ -68,8 +68,9 @@ def pmc_traffic(n_pairs, read_len):
     return (2.0 * val["FETCH_SIZE"] + val["WRITE_SIZE"]) * 1024.0, os.path.relpath(files[-1], ROOT)
 
 
-def end_to_end_leg(kb=2000, coverage=30):
+def end_to_end_leg(kb=2000, coverage=30, copies=8):
     """Simulate kb kilobases at the given coverage (one planted variant per kb, 100-bp reads with true CIGARs),
+    lay `copies` repeats of them end to end as one reference (simulating is far slower than calling),
     write BAM + .bai and FASTA + .fai, call them to a VCF with platypus_amd.runner, time the call."""
     import shutil
     import tempfile
@@ -81,6 +82,8 @@ def end_to_end_leg(kb=2000, coverage=30):
         genome = simulate.random_genome(rng, G)
         truth = simulate.plant_variants(rng, genome, G // 1000, spacing=600)
         reads = simulate.simulate_reads(rng, genome, truth, coverage=coverage, read_len=100)
+        genome, truth, reads = simulate.tile(genome, truth, reads, copies)
+        G *= copies
         fa = os.path.join(work, "ref.fa")
         with open(fa, "wb") as f:
             f.write(b">sim\n" + b"\n".join(genome[i:i + 60] for i in range(0, G, 60)) + b"\n")
@@ -105,7 +108,7 @@ def end_to_end_leg(kb=2000, coverage=30):
                 called.add(int(line.split("\t")[1]) - 1)
         return {"mbp_per_min": G / 1e6 / (best[1] / 60.0), "seconds": best[1],
                 "mbp_per_min_8_host_processes": G / 1e6 / (best[8] / 60.0), "seconds_8_host_processes": best[8],
-                "genome_kb": kb, "coverage": coverage,
+                "genome_kb": kb * copies, "simulated_kb": kb, "repeats": copies, "coverage": coverage,
                 "reads": int(len(reads["pos"])), "bam_mb": os.path.getsize(bam) / 1e6, "vcf_records": len(called),
                 "planted_variants": len(truth), "planted_found": sum(p in called for p, r, a, g in truth),
                 "processes": 1, "what": "simulated BAM + .bai and FASTA + .fai -> VCF, platypus_amd.runner"}
@@ -223,16 +226,18 @@ def main():
     }
 
     # ---- the consumer of the likelihood matrix (genotype likelihoods + EM per window), not part of
-    # the metric: kernel times of one pass over the same batch, one individual per window -----------
+    # the metric: kernel times of one pass over the same batch; one individual per window, except the
+    # joint-calling stream whose 550 reads per window are 50 individuals' 11 reads each ----------------
     caller = None
+    n_inds = 50 if args.workload == "joint" else 1
     try:
         ctx.launch()
-        ctx.upload_windows([H] * n_windows, [1] * n_windows, np.arange(n_windows, dtype=np.int64) * H * R,
-                           np.tile(np.array([0, R], dtype=np.int32), n_windows))
+        ctx.upload_windows([H] * n_windows, [n_inds] * n_windows, np.arange(n_windows, dtype=np.int64) * H * R,
+                           np.tile(np.arange(n_inds + 1, dtype=np.int32) * (R // n_inds), n_windows))
         ctx.caller_launch(100)
         ctx.sync()
         res = ctx.caller_fetch(genotype_post=False)
-        caller = {"windows": n_windows, "haplotypes": H, "individuals": 1,
+        caller = {"windows": n_windows, "haplotypes": H, "individuals": n_inds,
                   "setup_ms": ctx.kernel_ms(native.PG_K_CALLER_SETUP), "em_ms": ctx.kernel_ms(native.PG_K_CALLER_EM),
                   "em_iterations_mean": float(res["iters"].mean()), "em_iterations_max": int(res["iters"].max())}
     except native.PlatGpuError as e:                       # reported, never hidden

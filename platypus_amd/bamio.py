@@ -169,6 +169,62 @@ def _read_linear_index(path):
     return out
 
 
+def _write_records_packed(out, coff, rid, reads, isz, mpos, bins, linear):
+    """write_bam's record loop over whole arrays: records encoded by cbam.encodeRecords, cut into
+    BGZF blocks at record boundaries, the bin and linear indexes filled from the block offsets"""
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    blob, rec_off, ends, rbin = cbam.encodeRecords(
+        rid, np.ascontiguousarray(reads["seq"], dtype=np.uint8), np.ascontiguousarray(reads["qual"], dtype=np.uint8),
+        np.ascontiguousarray(reads["off"], dtype=np.int64), i32(reads["pos"]), i32(reads["mapq"]), i32(reads["flag"]),
+        np.ascontiguousarray(reads["cigar"], dtype=np.uint32), np.ascontiguousarray(reads["cigarOff"], dtype=np.int64),
+        i32(isz), i32(mpos))
+    n = len(ends)
+    voff = np.empty(n, dtype=np.int64)
+    raw = blob.tobytes()
+    cuts, i = [0], 0
+    while i < n:
+        j = int(np.searchsorted(rec_off, rec_off[i] + 0xff00, side="right")) - 1     # records i..j-1 fit one block
+        i = max(j, i + 1)
+        cuts.append(i)
+
+    def deflate(k):                                       # zlib works outside the interpreter lock
+        chunk = raw[rec_off[cuts[k]]:rec_off[cuts[k + 1]]]
+        comp = zlib.compressobj(1, zlib.DEFLATED, -15)
+        body = comp.compress(chunk) + comp.flush()
+        return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(body) + 25) + body +
+                struct.pack("<II", zlib.crc32(chunk) & 0xffffffff, len(chunk)))
+
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(min(16, os.cpu_count() or 1)) as pool:
+        for k, blk in enumerate(pool.map(deflate, range(len(cuts) - 1))):
+            i, j = cuts[k], cuts[k + 1]
+            out.write(blk)
+            voff[i:j] = (coff << 16) | (rec_off[i:j] - rec_off[i])
+            coff += len(blk)
+    vend = voff + (rec_off[1:] - rec_off[:-1])
+    order = np.argsort(rbin, kind="stable")
+    sb = rbin[order]
+    cuts = np.flatnonzero(np.diff(sb)) + 1
+    for lo, hi in zip(np.concatenate([[0], cuts]), np.concatenate([cuts, [n]])):
+        if hi > lo:
+            idx = order[lo:hi]
+            vo, ve = voff[idx], vend[idx]
+            brk = np.flatnonzero((ve[:-1] >> 16) != (vo[1:] >> 16)) + 1      # records of one block make one chunk
+            first_of = np.concatenate([[0], brk])
+            last_of = np.concatenate([brk, [len(idx)]]) - 1
+            bins[int(sb[lo])] = [[int(a), int(b)] for a, b in zip(vo[first_of], ve[last_of])]
+    pos = np.asarray(reads["pos"], dtype=np.int64)
+    last = np.maximum(ends.astype(np.int64), pos + 1) - 1
+    w0, w1 = pos >> 14, last >> 14
+    if n:
+        first = np.full(int(w1.max()) + 1, np.iinfo(np.int64).max, dtype=np.int64)
+        for d in range(int((w1 - w0).max()) + 1):
+            m = w0 + d <= w1
+            np.minimum.at(first, (w0 + d)[m], voff[m])
+        for w in np.flatnonzero(first != np.iinfo(np.int64).max):
+            linear[int(w)] = int(first[w])
+
+
 # ---------------------------------------------------------------------------------------------
 def _reg2bin(beg, end):
     end -= 1
@@ -219,6 +275,9 @@ def write_bam(path, refs, reads, sample="sample", names=None):
             coff += len(blk)
 
     flush()                                              # header in blocks of its own
+    if names is None:
+        _write_records_packed(out, coff, rid, reads, isz, mpos, bins, linear)
+        n = 0                                            # nothing left for the record-by-record loop
     for i in range(n):
         s0, s1 = int(reads["off"][i]), int(reads["off"][i + 1])
         c0, c1 = int(reads["cigarOff"][i]), int(reads["cigarOff"][i + 1])

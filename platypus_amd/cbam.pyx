@@ -101,3 +101,105 @@ def parseRecords(const unsigned char[::1] data, int refID, int start, int end):
         vo[i + 1] = b
     return (dict(seq=seq, qual=qual, off=off, pos=apos, mapq=amapq, flag=aflag, cigar=cigar, cigarOff=coff,
                  insertSize=isize, matePos=matepos), consumed, done)
+
+
+cdef inline int reg2bin(int beg, int end) noexcept nogil:
+    end -= 1
+    if beg >> 14 == end >> 14:
+        return 4681 + (beg >> 14)
+    if beg >> 17 == end >> 17:
+        return 585 + (beg >> 17)
+    if beg >> 20 == end >> 20:
+        return 73 + (beg >> 20)
+    if beg >> 23 == end >> 23:
+        return 9 + (beg >> 23)
+    if beg >> 26 == end >> 26:
+        return 1 + (beg >> 26)
+    return 0
+
+
+def encodeRecords(int refID, const unsigned char[::1] seq, const unsigned char[::1] qual, const long long[::1] off,
+                  const int[::1] pos, const int[::1] mapq, const int[::1] flag, const unsigned int[::1] cigar,
+                  const long long[::1] cigarOff, const int[::1] insertSize, const int[::1] matePos, long long firstName=0):
+    """The inverse of parseRecords for records without tags: uncompressed BAM alignment records
+    (block_size included) of reads named r<firstName + i>.  Returns (bytes of all records, int64
+    offsets of the records in them [n + 1], int32 end position of every alignment, int32 bin)."""
+    cdef Py_ssize_t n = pos.shape[0], i, j, k, p = 0, total = 0
+    cdef int lseq, ncig, lname, rend, b, op
+    cdef uint32_t cw, w
+    cdef int32_t v
+    cdef long long name_id
+    cdef char name[24]
+    cdef unsigned char code[256]
+    for i in range(256):
+        code[i] = 15
+    for i in range(16):
+        code[<unsigned char>BAM_BASES[i]] = <unsigned char>i
+    # sizes first: the name length depends on the number of digits
+    recOff = np.zeros(n + 1, dtype=np.int64)
+    ends = np.empty(n, dtype=np.int32)
+    bins = np.empty(n, dtype=np.int32)
+    cdef long long[::1] vo = recOff
+    cdef int[::1] ve = ends, vb = bins
+    for i in range(n):
+        name_id = firstName + i
+        lname = 3                                         # 'r', one digit, the terminating zero
+        while name_id >= 10:
+            name_id //= 10
+            lname += 1
+        lseq = <int>(off[i + 1] - off[i])
+        ncig = <int>(cigarOff[i + 1] - cigarOff[i])
+        total += 36 + lname + 4 * ncig + ((lseq + 1) >> 1) + lseq
+        vo[i + 1] = total
+    blob = np.zeros(total, dtype=np.uint8)
+    cdef unsigned char[::1] out = blob
+    for i in range(n):
+        p = vo[i]
+        lseq = <int>(off[i + 1] - off[i])
+        ncig = <int>(cigarOff[i + 1] - cigarOff[i])
+        lname = 0
+        name_id = firstName + i
+        while True:                                       # digits, last first
+            name[lname] = <char>(48 + name_id % 10)
+            lname += 1
+            name_id //= 10
+            if name_id == 0:
+                break
+        rend = pos[i]
+        for k in range(ncig):
+            cw = cigar[cigarOff[i] + k]
+            op = cw & 0xf
+            if op == 0 or op == 2 or op == 3:
+                rend += cw >> 4
+        ve[i] = rend
+        b = reg2bin(pos[i], rend if rend > pos[i] else pos[i] + 1)
+        vb[i] = b
+        v = <int32_t>(vo[i + 1] - p - 4); memcpy(&out[p], &v, 4)
+        v = refID; memcpy(&out[p + 4], &v, 4)
+        v = pos[i]; memcpy(&out[p + 8], &v, 4)
+        w = (<uint32_t>b << 16) | (<uint32_t>(mapq[i] & 0xff) << 8) | <uint32_t>(lname + 2); memcpy(&out[p + 12], &w, 4)
+        w = (<uint32_t>flag[i] << 16) | <uint32_t>ncig; memcpy(&out[p + 16], &w, 4)
+        v = lseq; memcpy(&out[p + 20], &v, 4)
+        v = refID if matePos[i] >= 0 else -1; memcpy(&out[p + 24], &v, 4)
+        v = matePos[i]; memcpy(&out[p + 28], &v, 4)
+        v = insertSize[i]; memcpy(&out[p + 32], &v, 4)
+        p += 36
+        out[p] = 114                                      # 'r'
+        for k in range(lname):
+            out[p + 1 + k] = <unsigned char>name[lname - 1 - k]
+        out[p + 1 + lname] = 0
+        p += lname + 2
+        for k in range(ncig):
+            cw = cigar[cigarOff[i] + k]
+            memcpy(&out[p + 4 * k], &cw, 4)
+        p += 4 * ncig
+        j = off[i]
+        for k in range(lseq):
+            if k & 1:
+                out[p + (k >> 1)] |= code[seq[j + k]]
+            else:
+                out[p + (k >> 1)] = code[seq[j + k]] << 4
+        p += (lseq + 1) >> 1
+        for k in range(lseq):
+            out[p + k] = qual[j + k]
+    return blob, recOff, ends, bins

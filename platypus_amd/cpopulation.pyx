@@ -383,7 +383,8 @@ cdef class WindowBatch:
         cdef int32_t* best = <int32_t*>malloc((nIndTot + 1) * sizeof(int32_t))
         cdef double* val = <double*>malloc((nIndTot + 1) * sizeof(double))
         cdef double* post = <double*>malloc((nCells + 1) * sizeof(double))
-        cdef int64_t hi = 0, ri = 0, ii = 0, oi = 0, ci = 0
+        cdef int64_t hi = 0, ri = 0, ii = 0, oi = 0, ci = 0, nPairs = 0, nCellsDP = 0
+        cdef float kms[5]
         cdef list out = []
         global g_generation
         try:
@@ -433,6 +434,16 @@ cdef class WindowBatch:
             check(ctx, pg_caller_launch(ctx, maxIters))
             check(ctx, pg_caller_fetch(ctx, freq, iters, change, best, val, post))
             t3 = time.perf_counter()
+            for w in range(5):                                    # anchor, alignment, genotype, setup, EM (platgpu.h)
+                kms[w] = 0.0
+                pg_kernel_time_ms(ctx, w, &kms[w])
+            for w in range(nW):
+                nPairs += <int64_t>b_nh[w] * b_nr[w]
+            ri = 0
+            for w in range(nW):                                   # cells as the reference's loop executes them (align.c:106)
+                for r in range(b_nr[w]):
+                    nCellsDP += <int64_t>b_nh[w] * 16 * (roff[ri + 1] - roff[ri] + 8)
+                    ri += 1
             hi = 0; ii = 0; ci = 0
             for w in range(nW):
                 haps, bufs, counts, ptrs = self.windows[w]
@@ -444,7 +455,8 @@ cdef class WindowBatch:
                 ci += <int64_t>len(bufs) * (len(haps) * (len(haps) + 1) // 2)
             t4 = time.perf_counter()
             self.timings = dict(pack=t1 - t0, upload=t2 - t1, device=t3 - t2, unpack=t4 - t3,
-                                windows=nW, haplotypes=int(nHapTot), reads=int(nReadTot))
+                                windows=nW, haplotypes=int(nHapTot), reads=int(nReadTot), pairs=int(nPairs),
+                                cells=int(nCellsDP), anchor_ms=kms[0], align_ms=kms[1], setup_ms=kms[3], em_ms=kms[4])
         finally:
             free(hoff); free(hstart); free(hvl); free(hbuf); free(roff); free(rpos); free(rmq); free(sbuf); free(qbuf)
             free(b_hlo); free(b_nh); free(b_rlo); free(b_nr); free(w_ni); free(base); free(ioff); free(nreads)

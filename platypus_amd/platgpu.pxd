@@ -34,3 +34,4 @@ cdef extern from "platgpu.h":
                         const int32_t* read_lo, const int32_t* n_reads, int64_t* pair_base)
     int pg_hash_sequence(pg_ctx* ctx, const char* seq, int len, int32_t* table)
     int pg_map_read(pg_ctx* ctx, const char* read, int read_len, int seq_len, const int32_t* table, int32_t* position)
+    int pg_kernel_time_ms(pg_ctx* ctx, int which, float* ms)

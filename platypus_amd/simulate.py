@@ -138,3 +138,20 @@ def buffer_of(reads, start, end, **kw):
     return cwindow.bamReadBuffer.fromAlignments(reads["chrom"], start, end, reads["seq"], reads["qual"], reads["off"],
                                                 reads["pos"], reads["mapq"], reads["flag"], reads["cigar"],
                                                 reads["cigarOff"], **kw)
+
+
+def tile(genome, variants, reads, copies):
+    """`copies` repeats of one simulated stretch laid end to end as ONE longer reference: the
+    sequence repeated, every planted variant and every read shifted by multiples of its length.
+    Simulating is far slower than calling, so long references for timing runs are built this way;
+    windows are local, so the repeats do not interact."""
+    G, n = len(genome), len(reads["pos"])
+    out = dict(chrom=reads["chrom"])
+    for k in ("seq", "qual", "mapq", "flag", "cigar"):
+        out[k] = np.tile(reads[k], copies)
+    out["pos"] = np.concatenate([reads["pos"].astype(np.int64) + c * G for c in range(copies)]).astype(np.int32)
+    for k, base in (("off", "seq"), ("cigarOff", "cigar")):
+        step = len(reads[base])
+        out[k] = np.concatenate([reads[k][:-1] + c * step for c in range(copies)] + [np.array([copies * step])]).astype(np.int64)
+    truth = [(p + c * G, rem, add, gt) for c in range(copies) for p, rem, add, gt in variants]
+    return genome * copies, truth, out
