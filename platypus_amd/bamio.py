@@ -14,8 +14,24 @@ from platypus_amd import cbam
 _EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
 
 
-def _read_block(f):
-    """one BGZF block at the file position: (uncompressed bytes, compressed size) or (b'', 0) at EOF"""
+_POOL = None
+
+
+def _inflate_all(bodies):
+    """raw deflate payloads -> their contents, inflated on a few threads (zlib works outside the
+    interpreter lock; one thread inflates ~300 MB/s, less than the record decoder and the caller consume)"""
+    global _POOL
+    if len(bodies) < 8:
+        return [zlib.decompress(b, -15) for b in bodies]
+    if _POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL = ThreadPoolExecutor(int(os.environ.get("PLATYPUS_AMD_INFLATE_THREADS", "4")))
+    return list(_POOL.map(lambda b: zlib.decompress(b, -15), bodies))
+
+
+def _read_block(f, raw=False):
+    """one BGZF block at the file position: (uncompressed bytes, compressed size) or (b'', 0) at EOF;
+    raw=True returns the deflate payload instead of inflating it"""
     head = f.read(18)
     if len(head) < 18:
         return b"", 0
@@ -33,6 +49,8 @@ def _read_block(f):
     if bsize is None:
         raise IOError("BGZF block without a BC field")
     body = f.read(bsize + 1 - 12 - xlen)
+    if raw:
+        return body[:-8], bsize + 1
     return zlib.decompress(body[:-8], -15), bsize + 1
 
 
@@ -120,15 +138,15 @@ class BamReader(object):
             del buf[:used]
             if done:
                 break
-            grew = False
-            for _ in range(64):                          # up to 4 MiB per round
-                blk, size = _read_block(self.f)
+            bodies = []
+            for _ in range(128):                         # up to 8 MiB per round
+                body, size = _read_block(self.f, raw=True)
                 if not size:
                     break
-                buf += blk
-                grew = True
-            if not grew:
+                bodies.append(body)
+            if not bodies:
                 break
+            buf += b"".join(_inflate_all(bodies))
         return _concat(parts)
 
 

@@ -43,7 +43,7 @@ def build(force=False, verbose=True):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd, cwd=ROOT)
-        cc = ["gcc", "-O2", "-fPIC", "-shared", "-fno-strict-aliasing", "-Wno-unused-function",
+        cc = ["gcc", "-O3", "-fPIC", "-shared", "-fno-strict-aliasing", "-Wno-unused-function",
               "-DNPY_NO_DEPRECATED_API=NPY_1_7_API_VERSION"] + ["-I" + i for i in inc] + \
              ["-o", _ext_path(mod), c_file, "-L" + os.path.join(HERE, "lib"), "-lplatgpu",
               "-Wl,-rpath,$ORIGIN/lib", "-lm"]

@@ -6,6 +6,7 @@ import numpy as np
 
 from libc.stdint cimport int32_t, uint32_t, uint16_t, uint8_t, int64_t
 from libc.string cimport memcpy
+from libc.stdlib cimport malloc, realloc, free
 
 cdef const char* BAM_BASES = b"=ACMGRSVTWYHKDBN"
 
@@ -20,37 +21,50 @@ def parseRecords(const unsigned char[::1] data, int refID, int start, int end):
     cdef uint32_t binmq, flagnc, cw
     cdef int lname, mapq, ncig, flag, k, op, ln
     cdef bint done = False
-    # first pass: count
-    cdef Py_ssize_t nrec = 0, nbases = 0, ncigar = 0, q
-    cdef list starts = []
-    while p + 4 <= n:
-        memcpy(&block, &data[p], 4)
-        if p + 4 + block > n:
-            break
-        memcpy(&rid, &data[p + 4], 4)
-        memcpy(&pos, &data[p + 8], 4)
-        memcpy(&binmq, &data[p + 12], 4)
-        memcpy(&flagnc, &data[p + 16], 4)
-        memcpy(&lseq, &data[p + 20], 4)
-        lname = binmq & 0xff
-        ncig = flagnc & 0xffff
-        if rid > refID or rid < 0 or (rid == refID and pos >= end):
-            done = True
-            break
-        if rid == refID:
-            rend = pos
-            q = p + 36 + lname
-            for k in range(ncig):
-                memcpy(&cw, &data[q + 4 * k], 4)
-                op = cw & 0xf
-                if op == 0 or op == 2 or op == 3 or op == 7 or op == 8:
-                    rend += cw >> 4
-            if rend > start or (rend == pos and pos >= start):
-                starts.append(p)
-                nrec += 1
-                nbases += lseq
-                ncigar += ncig
-        p += 4 + block
+    # first pass: count (without the interpreter lock: the caller's other thread keeps running)
+    cdef Py_ssize_t nrec = 0, nbases = 0, ncigar = 0, q, cap = 4096
+    cdef Py_ssize_t* starts = <Py_ssize_t*>malloc(cap * sizeof(Py_ssize_t))
+    cdef Py_ssize_t* grown
+    cdef bint oom = starts == NULL
+    with nogil:
+        while p + 4 <= n and not oom:
+            memcpy(&block, &data[p], 4)
+            if p + 4 + block > n:
+                break
+            memcpy(&rid, &data[p + 4], 4)
+            memcpy(&pos, &data[p + 8], 4)
+            memcpy(&binmq, &data[p + 12], 4)
+            memcpy(&flagnc, &data[p + 16], 4)
+            memcpy(&lseq, &data[p + 20], 4)
+            lname = binmq & 0xff
+            ncig = flagnc & 0xffff
+            if rid > refID or rid < 0 or (rid == refID and pos >= end):
+                done = True
+                break
+            if rid == refID:
+                rend = pos
+                q = p + 36 + lname
+                for k in range(ncig):
+                    memcpy(&cw, &data[q + 4 * k], 4)
+                    op = cw & 0xf
+                    if op == 0 or op == 2 or op == 3 or op == 7 or op == 8:
+                        rend += cw >> 4
+                if rend > start or (rend == pos and pos >= start):
+                    if nrec == cap:
+                        grown = <Py_ssize_t*>realloc(starts, 2 * cap * sizeof(Py_ssize_t))
+                        if grown == NULL:
+                            oom = True
+                            break
+                        starts = grown
+                        cap *= 2
+                    starts[nrec] = p
+                    nrec += 1
+                    nbases += lseq
+                    ncigar += ncig
+            p += 4 + block
+    if oom:
+        free(starts)
+        raise MemoryError()
     consumed = p
     seq = np.empty(nbases, dtype=np.uint8)
     qual = np.empty(nbases, dtype=np.uint8)
@@ -67,38 +81,40 @@ def parseRecords(const unsigned char[::1] data, int refID, int start, int end):
     cdef int[::1] vp = apos, vm = amapq, vf = aflag, vi = isize, vmp = matepos
     cdef unsigned int[::1] vc = cigar
     cdef Py_ssize_t i, b = 0, c = 0, j
-    for i in range(nrec):
-        p = starts[i]
-        memcpy(&pos, &data[p + 8], 4)
-        memcpy(&binmq, &data[p + 12], 4)
-        memcpy(&flagnc, &data[p + 16], 4)
-        memcpy(&lseq, &data[p + 20], 4)
-        memcpy(&mpos, &data[p + 28], 4)
-        memcpy(&tlen, &data[p + 32], 4)
-        lname = binmq & 0xff
-        ncig = flagnc & 0xffff
-        vp[i] = pos
-        vm[i] = (binmq >> 8) & 0xff
-        vf[i] = flagnc >> 16
-        vi[i] = tlen
-        vmp[i] = mpos
-        q = p + 36 + lname
-        for k in range(ncig):
-            memcpy(&cw, &data[q + 4 * k], 4)
-            op = cw & 0xf
-            if op == 7 or op == 8:                      # '=' and 'X' are matches to this caller
-                cw = (cw & 0xfffffff0u)
-            vc[c + k] = cw
-        c += ncig
-        vco[i + 1] = c
-        q += 4 * ncig
-        for j in range(lseq):
-            vs[b + j] = BAM_BASES[(data[q + (j >> 1)] >> (4 * (1 - (j & 1)))) & 0xf]
-        q += (lseq + 1) >> 1
-        for j in range(lseq):
-            vq[b + j] = data[q + j]
-        b += lseq
-        vo[i + 1] = b
+    with nogil:
+        for i in range(nrec):
+            p = starts[i]
+            memcpy(&pos, &data[p + 8], 4)
+            memcpy(&binmq, &data[p + 12], 4)
+            memcpy(&flagnc, &data[p + 16], 4)
+            memcpy(&lseq, &data[p + 20], 4)
+            memcpy(&mpos, &data[p + 28], 4)
+            memcpy(&tlen, &data[p + 32], 4)
+            lname = binmq & 0xff
+            ncig = flagnc & 0xffff
+            vp[i] = pos
+            vm[i] = (binmq >> 8) & 0xff
+            vf[i] = flagnc >> 16
+            vi[i] = tlen
+            vmp[i] = mpos
+            q = p + 36 + lname
+            for k in range(ncig):
+                memcpy(&cw, &data[q + 4 * k], 4)
+                op = cw & 0xf
+                if op == 7 or op == 8:                      # '=' and 'X' are matches to this caller
+                    cw = (cw & 0xfffffff0u)
+                vc[c + k] = cw
+            c += ncig
+            vco[i + 1] = c
+            q += 4 * ncig
+            for j in range(lseq):
+                vs[b + j] = BAM_BASES[(data[q + (j >> 1)] >> (4 * (1 - (j & 1)))) & 0xf]
+            q += (lseq + 1) >> 1
+            for j in range(lseq):
+                vq[b + j] = data[q + j]
+            b += lseq
+            vo[i + 1] = b
+    free(starts)
     return (dict(seq=seq, qual=qual, off=off, pos=apos, mapq=amapq, flag=aflag, cigar=cigar, cigarOff=coff,
                  insertSize=isize, matePos=matepos), consumed, done)
 

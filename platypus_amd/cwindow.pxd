@@ -14,4 +14,7 @@ cdef class bamReadBuffer:
     cdef cAlignedRead** windowStart                 # the current window's reads: [windowStart, windowEnd)
     cdef cAlignedRead** windowEnd
     cdef object keepAlive
+    cdef char* slabBytes                            # fromAlignments: bases and qualities of all reads in one block,
+    cdef int* slabInts                              # CIGAR operations and lengths in another,
+    cdef cAlignedRead* slabReads                    # the records in a third
     cdef setWindowPointers(self, int start, int end)

@@ -11,7 +11,7 @@ is what a BAM reader or a simulator hands over.
 import numpy as np
 
 from libc.stdlib cimport malloc, free, calloc
-from libc.string cimport memcpy
+from libc.string cimport memcpy, memset
 
 from platypus_amd.samtoolsWrapper cimport cAlignedRead
 
@@ -30,7 +30,7 @@ cdef int bisectReadsLeft(cAlignedRead** reads, int testPos, int nReads):
 
 
 cdef int checkAndTrimRead(cAlignedRead* theRead, cAlignedRead* theLastRead, int maxBadQualBases,
-                          int minGoodQualBases):
+                          int minGoodQualBases) noexcept nogil:
     """platypus/cwindow.pyx:74-146: 0 = drop the record; otherwise its low-quality ends (and, for a
     fragment shorter than two reads, the forward read's overlap with its mate) get quality 0."""
     cdef int index
@@ -130,7 +130,8 @@ cdef class bamReadBuffer:
         cdef const int[::1] isz = np.ascontiguousarray(insertSize if insertSize is not None else np.zeros(n), dtype=np.int32)
         cdef const int[::1] mp = np.ascontiguousarray(matePos if matePos is not None else np.full(n, -1), dtype=np.int32)
         cdef bamReadBuffer self = bamReadBuffer.__new__(bamReadBuffer)
-        cdef int i, k, rl, nc, count = 0, index
+        cdef int i, k, rl, nc, count = 0, index, b5, b10, b15, b20
+        cdef signed char qv
         cdef cAlignedRead* r
         cdef cAlignedRead* last
         self.chromBytes = chrom
@@ -140,56 +141,80 @@ cdef class bamReadBuffer:
         self.longestRead = 0
         self.nReads = 0
         self.cReads = <cAlignedRead**>malloc((n + 1) * sizeof(cAlignedRead*))
-        for i in range(n):
-            if m[i] < minMapQual:                                   # cwindow.pyx:188-190
-                continue
-            rl = <int>(o[i + 1] - o[i])
-            if rl == 0 or q[o[i]] == 0xff:                          # samtoolsWrapper.pyx:712-719
-                continue
-            r = <cAlignedRead*>calloc(1, sizeof(cAlignedRead))
-            r.seq = <char*>calloc(rl + 1, 1)
-            r.qual = <char*>calloc(rl + 1, 1)
-            memcpy(r.seq, &s[o[i]], rl)
-            memcpy(r.qual, &q[o[i]], rl)
-            for k in range(rl):
-                if r.qual[k] < 5: r.nQualsBelow5 += 1
-                if r.qual[k] < 10: r.nQualsBelow10 += 1
-                if r.qual[k] < 15: r.nQualsBelow15 += 1
-                if r.qual[k] < 20: r.nQualsBelow20 += 1
-            r.pos = p[i]; r.rlen = rl; r.mapq = m[i]
-            nc = <int>(co[i + 1] - co[i])
-            r.cigarLen = nc
-            r.cigarOps = <int*>malloc((nc + 1) * sizeof(int))
-            r.cigarLens = <int*>malloc((nc + 1) * sizeof(int))
-            r.end = r.pos
-            for k in range(nc):
-                r.cigarOps[k] = cg[co[i] + k] & 0xf
-                r.cigarLens[k] = cg[co[i] + k] >> 4
-                if r.cigarOps[k] == 0 or r.cigarOps[k] == 2 or r.cigarOps[k] == 3:
-                    r.end += r.cigarLens[k]                          # samtoolsWrapper.pyx:773-774
-            r.isReverse = (fl[i] & 0x10) != 0
-            r.isDuplicate = (fl[i] & 0x400) != 0
-            r.isUnMapped = (fl[i] & 0x4) != 0
-            r.insertSize = isz[i]
-            r.mateIsUnmapped = (fl[i] & 0x8) != 0
-            r.mateIsReverse = (fl[i] & 0x20) != 0
-            r.matePos = mp[i]
-            r.isReadOne = (fl[i] & 0x40) != 0
-            r.isPaired = (fl[i] & 0x1) != 0
-            last = self.cReads[count - 1] if count > 0 else NULL
-            if not checkAndTrimRead(r, last, maxBadQualBases, minGoodQualBases):
-                free(r.seq); free(r.qual); free(r.cigarOps); free(r.cigarLens); free(r)
-                continue
-            if count > 0 and r.pos < self.cReads[count - 1].pos:
-                free(r.seq); free(r.qual); free(r.cigarOps); free(r.cigarLens); free(r)
-                self.nReads = count
-                raise ValueError("records are not sorted by position")
-            if r.end - r.pos > self.longestRead:
-                self.longestRead = r.end - r.pos
-            self.cReads[count] = r
-            count += 1
-            if count > maxReads:                                     # cwindow.pyx:221-223
-                break
+        # three blocks for the whole buffer instead of five allocations per read; a dropped record's
+        # space is taken by the next one
+        self.slabBytes = <char*>malloc(2 * (<size_t>s.shape[0] + n) + 2)
+        self.slabInts = <int*>malloc((2 * (<size_t>cg.shape[0] + n) + 2) * sizeof(int))
+        self.slabReads = <cAlignedRead*>malloc((<size_t>n + 1) * sizeof(cAlignedRead))
+        if self.cReads == NULL or self.slabBytes == NULL or self.slabInts == NULL or self.slabReads == NULL:
+            raise MemoryError()
+        cdef bint unsorted = False
+        cdef cAlignedRead** reads = self.cReads
+        cdef char* bytesAt = self.slabBytes
+        cdef int* intsAt = self.slabInts
+        cdef cAlignedRead* recs = self.slabReads
+        cdef int longest = 0
+        with nogil:                                                  # a helper thread can build the next buffer meanwhile
+            for i in range(n):
+                if m[i] < minMapQual:                                   # cwindow.pyx:188-190
+                    continue
+                rl = <int>(o[i + 1] - o[i])
+                if rl == 0 or q[o[i]] == 0xff:                          # samtoolsWrapper.pyx:712-719
+                    continue
+                r = recs + count
+                memset(r, 0, sizeof(cAlignedRead))
+                r.seq = bytesAt
+                r.qual = bytesAt + rl + 1
+                memcpy(r.seq, &s[o[i]], rl)
+                memcpy(r.qual, &q[o[i]], rl)
+                r.seq[rl] = 0
+                r.qual[rl] = 0
+                b5 = b10 = b15 = b20 = 0
+                for k in range(rl):                                     # branch-free counts in registers
+                    qv = r.qual[k]
+                    b5 += qv < 5
+                    b10 += qv < 10
+                    b15 += qv < 15
+                    b20 += qv < 20
+                r.nQualsBelow5 = b5; r.nQualsBelow10 = b10; r.nQualsBelow15 = b15; r.nQualsBelow20 = b20
+                r.pos = p[i]; r.rlen = rl; r.mapq = m[i]
+                nc = <int>(co[i + 1] - co[i])
+                r.cigarLen = nc
+                r.cigarOps = intsAt
+                r.cigarLens = intsAt + nc + 1
+                r.end = r.pos
+                for k in range(nc):
+                    r.cigarOps[k] = cg[co[i] + k] & 0xf
+                    r.cigarLens[k] = cg[co[i] + k] >> 4
+                    if r.cigarOps[k] == 0 or r.cigarOps[k] == 2 or r.cigarOps[k] == 3:
+                        r.end += r.cigarLens[k]                          # samtoolsWrapper.pyx:773-774
+                r.isReverse = (fl[i] & 0x10) != 0
+                r.isDuplicate = (fl[i] & 0x400) != 0
+                r.isUnMapped = (fl[i] & 0x4) != 0
+                r.insertSize = isz[i]
+                r.mateIsUnmapped = (fl[i] & 0x8) != 0
+                r.mateIsReverse = (fl[i] & 0x20) != 0
+                r.matePos = mp[i]
+                r.isReadOne = (fl[i] & 0x40) != 0
+                r.isPaired = (fl[i] & 0x1) != 0
+                last = reads[count - 1] if count > 0 else NULL
+                if not checkAndTrimRead(r, last, maxBadQualBases, minGoodQualBases):
+                    continue
+                if count > 0 and r.pos < reads[count - 1].pos:
+                    unsorted = True
+                    break
+                if r.end - r.pos > longest:
+                    longest = r.end - r.pos
+                reads[count] = r
+                count += 1
+                bytesAt += 2 * (rl + 1)
+                intsAt += 2 * (nc + 1)
+                if count > maxReads:                                     # cwindow.pyx:221-223
+                    break
+        self.longestRead = longest
+        if unsorted:
+            self.nReads = count
+            raise ValueError("records are not sorted by position")
         self.nReads = count
         self.start = self.cReads
         self.end = self.cReads + count
@@ -199,7 +224,9 @@ cdef class bamReadBuffer:
 
     def __dealloc__(self):
         cdef int i
-        if self.cReads != NULL:
+        if self.slabReads != NULL or self.slabBytes != NULL or self.slabInts != NULL:
+            free(self.slabBytes); free(self.slabInts); free(self.slabReads); free(self.cReads)
+        elif self.cReads != NULL:
             for i in range(self.nReads):
                 free(self.cReads[i].seq)
                 free(self.cReads[i].qual)

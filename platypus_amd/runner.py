@@ -36,9 +36,9 @@ def parse_regions(text, fasta):
 
 
 def call_chunks(chunks, args, tmpdir):
-    """Calls every chunk of the list into its own temporary file.  The reads of the next buffer are
-    fetched (file reads and BGZF inflation, both outside the interpreter lock) on a helper thread
-    while the current buffer is being called."""
+    """Calls every chunk of the list into its own temporary file.  The read buffers of the next
+    stretch are prepared on a helper thread (file reads, BGZF inflation, record decoding, filtering and
+    trimming all run outside the interpreter lock) while the current stretch is being called."""
     from concurrent.futures import ThreadPoolExecutor
     from platypus_amd import bamio, pipeline, simulate, vcfout
     from platypus_amd.fastafile import FastaFile
@@ -48,9 +48,15 @@ def call_chunks(chunks, args, tmpdir):
     opts = pipeline.Options(**{k: getattr(args, k) for k in vars(pipeline.Options()) if hasattr(args, k)})
     units = [(ch, s, min(s + args.bufferSize, ch[2])) for ch in chunks for s in range(ch[1], ch[2], args.bufferSize)]
 
-    def load(unit):
+    def load(unit):                                       # fetch, inflate, decode, filter and trim: all outside the lock
         (chrom, _, _), s, e = unit
-        return [r.fetch(chrom, s, e) for r in readers]
+        bufs = []
+        for r in readers:
+            reads = r.fetch(chrom, s, e)
+            reads["chrom"] = chrom.encode()
+            bufs.append(simulate.buffer_of(reads, s, e, minMapQual=opts.minMapQual, maxReads=int(opts.maxReads),
+                                           minGoodQualBases=opts.minGoodQualBases, maxBadQualBases=opts.maxBadQualBases))
+        return bufs
 
     header = "\n".join(vcfout.header(samples, " ".join(sys.argv[1:]))) + "\n"
     for ch in chunks:
@@ -61,7 +67,7 @@ def call_chunks(chunks, args, tmpdir):
     with ThreadPoolExecutor(1) as pool:
         pending = pool.submit(load, units[0]) if units else None
         for i, (ch, s, e) in enumerate(units):
-            fetched = pending.result()
+            bufs = pending.result()
             pending = pool.submit(load, units[i + 1]) if i + 1 < len(units) else None
             if ch is not current:
                 if out is not None:
@@ -70,11 +76,6 @@ def call_chunks(chunks, args, tmpdir):
                 out.write(header)
                 current = ch
             chrom = ch[0]
-            bufs = []
-            for reads in fetched:
-                reads["chrom"] = chrom.encode()
-                bufs.append(simulate.buffer_of(reads, s, e, minMapQual=opts.minMapQual, maxReads=int(opts.maxReads),
-                                               minGoodQualBases=opts.minGoodQualBases, maxBadQualBases=opts.maxBadQualBases))
             if sum(b.readCount for b in bufs) > opts.maxReads:            # variantcaller.pyx:84-88
                 continue
             for c in pipeline.callRegion(chrom.encode(), s, e, bufs, fa, opts):
