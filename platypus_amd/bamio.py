@@ -11,27 +11,13 @@ import numpy as np
 
 from platypus_amd import cbam
 
+_EMPTY = np.zeros(0, dtype=np.uint8)
 _EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
 
 
-_POOL = None
-
-
-def _inflate_all(bodies):
-    """raw deflate payloads -> their contents, inflated on a few threads (zlib works outside the
-    interpreter lock; one thread inflates ~300 MB/s, less than the record decoder and the caller consume)"""
-    global _POOL
-    if len(bodies) < 8:
-        return [zlib.decompress(b, -15) for b in bodies]
-    if _POOL is None:
-        from concurrent.futures import ThreadPoolExecutor
-        _POOL = ThreadPoolExecutor(int(os.environ.get("PLATYPUS_AMD_INFLATE_THREADS", "4")))
-    return list(_POOL.map(lambda b: zlib.decompress(b, -15), bodies))
-
-
-def _read_block(f, raw=False):
-    """one BGZF block at the file position: (uncompressed bytes, compressed size) or (b'', 0) at EOF;
-    raw=True returns the deflate payload instead of inflating it"""
+def _read_block(f):
+    """one BGZF block at the file position: (uncompressed bytes, compressed size) or (b'', 0) at EOF
+    (header parsing; the record stream goes through cbam.inflateBlocks)"""
     head = f.read(18)
     if len(head) < 18:
         return b"", 0
@@ -49,8 +35,6 @@ def _read_block(f, raw=False):
     if bsize is None:
         raise IOError("BGZF block without a BC field")
     body = f.read(bsize + 1 - 12 - xlen)
-    if raw:
-        return body[:-8], bsize + 1
     return zlib.decompress(body[:-8], -15), bsize + 1
 
 
@@ -88,6 +72,7 @@ class BamReader(object):
         # virtual offset of the first alignment
         self._first = (self.f.tell(), None) if pos == len(data) else None
         self._header_tail = data[pos:]
+        self._header_bytes = pos                      # uncompressed size of the header
         self._after_header = self.f.tell()
         self.sample = None
         for line in self.text.split(b"\n"):
@@ -125,28 +110,31 @@ class BamReader(object):
             voff = None
         if voff is None:
             self.f.seek(self._after_header)
-            buf = bytearray(self._header_tail)
+            tail = np.frombuffer(self._header_tail, dtype=np.uint8)
+            skip = 0
         else:
             self.f.seek(voff >> 16)
-            blk, _ = _read_block(self.f)
-            buf = bytearray(blk[voff & 0xffff:])
-        parts = []
+            tail = _EMPTY
+            skip = voff & 0xffff                          # the first record starts inside the first block
+        parts, raw = [], b""
         while True:
-            arrays, used, done = cbam.parseRecords(np.frombuffer(bytes(buf), dtype=np.uint8), rid, start, end)
+            chunk = self.f.read(4 << 20)
+            raw = raw + chunk if raw else chunk
+            # whole blocks inflated behind what the last round left over, then decoded: both in C without the
+            # interpreter lock, so a helper thread doing this does not hold up the thread that calls variants
+            data, eaten = cbam.inflateBlocks(np.frombuffer(raw, dtype=np.uint8), tail)
+            raw = raw[eaten:]
+            if skip:
+                if len(data) < skip and chunk:
+                    tail = data
+                    continue
+                data, skip = data[skip:], 0
+            arrays, used, done = cbam.parseRecords(data, rid, start, end)
             if len(arrays["pos"]):
                 parts.append(arrays)
-            del buf[:used]
-            if done:
+            tail = data[used:]
+            if done or not chunk:
                 break
-            bodies = []
-            for _ in range(128):                         # up to 8 MiB per round
-                body, size = _read_block(self.f, raw=True)
-                if not size:
-                    break
-                bodies.append(body)
-            if not bodies:
-                break
-            buf += b"".join(_inflate_all(bodies))
         return _concat(parts)
 
 

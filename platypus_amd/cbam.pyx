@@ -219,3 +219,94 @@ def encodeRecords(int refID, const unsigned char[::1] seq, const unsigned char[:
         for k in range(lseq):
             out[p + k] = qual[j + k]
     return blob, recOff, ends, bins
+
+
+cdef extern from "zlib.h":
+    ctypedef struct z_stream:
+        const unsigned char* next_in
+        unsigned int avail_in
+        unsigned char* next_out
+        unsigned int avail_out
+        void* zalloc
+        void* zfree
+        void* opaque
+    int inflateInit2(z_stream* strm, int windowBits) nogil
+    int inflate(z_stream* strm, int flush) nogil
+    int inflateReset(z_stream* strm) nogil
+    int inflateEnd(z_stream* strm) nogil
+    enum:
+        Z_OK
+        Z_STREAM_END
+        Z_FINISH
+
+
+def inflateBlocks(const unsigned char[::1] raw, const unsigned char[::1] prefix):
+    """Every complete BGZF block at the start of `raw`, inflated one after the other behind a copy of
+    `prefix` (what the caller had left over), in one call that does not hold the interpreter lock.
+    Returns (uint8 array, bytes of `raw` consumed); a trailing incomplete block is left unconsumed."""
+    cdef Py_ssize_t n = raw.shape[0], p = 0, k, q, total = prefix.shape[0], xlen, bsize, at
+    cdef Py_ssize_t nblocks = 0
+    cdef uint32_t isize
+    cdef int bad = 0, rc
+    # sizes first
+    while p + 18 <= n:
+        if raw[p] != 0x1f or raw[p + 1] != 0x8b or raw[p + 2] != 8 or raw[p + 3] != 4:
+            raise IOError("not a BGZF block")
+        xlen = raw[p + 10] | (raw[p + 11] << 8)
+        if p + 12 + xlen > n:
+            break
+        bsize = -1
+        k = p + 12
+        while k + 4 <= p + 12 + xlen:
+            if raw[k] == 66 and raw[k + 1] == 67:
+                bsize = raw[k + 4] | (raw[k + 5] << 8)
+            k += 4 + (raw[k + 2] | (raw[k + 3] << 8))
+        if bsize < 0:
+            raise IOError("BGZF block without a BC field")
+        if p + bsize + 1 > n:
+            break
+        memcpy(&isize, &raw[p + bsize + 1 - 4], 4)
+        total += isize
+        nblocks += 1
+        p += bsize + 1
+    consumed = p
+    out = np.empty(total, dtype=np.uint8)
+    cdef unsigned char[::1] vo = out
+    cdef z_stream zs
+    if prefix.shape[0]:
+        memcpy(&vo[0], &prefix[0], prefix.shape[0])
+    if nblocks == 0:
+        return out, consumed
+    with nogil:
+        zs.zalloc = NULL; zs.zfree = NULL; zs.opaque = NULL
+        zs.next_in = NULL; zs.avail_in = 0
+        if inflateInit2(&zs, -15) != Z_OK:
+            bad = 1
+        else:
+            p = 0
+            at = prefix.shape[0]
+            for k in range(nblocks):
+                xlen = raw[p + 10] | (raw[p + 11] << 8)
+                bsize = -1
+                q = p + 12
+                while q + 4 <= p + 12 + xlen:
+                    if raw[q] == 66 and raw[q + 1] == 67:
+                        bsize = raw[q + 4] | (raw[q + 5] << 8)
+                    q += 4 + (raw[q + 2] | (raw[q + 3] << 8))
+                memcpy(&isize, &raw[p + bsize + 1 - 4], 4)
+                if isize:
+                    zs.next_in = &raw[p + 12 + xlen]
+                    zs.avail_in = <unsigned int>(bsize + 1 - 12 - xlen - 8)
+                    zs.next_out = &vo[at]
+                    zs.avail_out = isize
+                    rc = inflate(&zs, Z_FINISH)
+                    if rc != Z_STREAM_END or zs.avail_out != 0:
+                        bad = 2
+                        break
+                    inflateReset(&zs)
+                at += isize
+                p += bsize + 1
+            inflateEnd(&zs)
+    if bad:
+        raise IOError("corrupt BGZF block" if bad == 2 else "zlib could not be initialised")
+    return out, consumed

@@ -14,6 +14,7 @@ class FastaFile(object):
         self.refs = {}
         self._mem = None
         self._file = None
+        self._cache = None                                        # (name, begin, end, bytes)
         if sequences is not None:
             self._mem = {}
             for name, seq in sequences.items():
@@ -54,7 +55,22 @@ class FastaFile(object):
         self._file.seek(self._offset(t, pos))
         return self._file.read(1).upper()
 
+    def setCacheSequence(self, seqName, beginPos, endPos):
+        """fastafile.pyx:112-139: keep [beginPos, endPos) of one sequence in memory; getSequence
+        answers from it while the request lies inside (the region caller asks for the region
+        +- 25 kb, variantcaller.pyx:214)"""
+        t = self.refs[seqName]
+        beginPos = max(0, beginPos)
+        endPos = min(t.SeqLength - 1, endPos)
+        if endPos < beginPos:
+            raise IndexError("Cannot have beginPos = %s, endPos = %s" % (beginPos, endPos))
+        self._cache = None
+        self._cache = (seqName, beginPos, endPos, self.getSequence(seqName, beginPos, endPos))
+
     def getSequence(self, seqName, beginPos, endPos):
+        c = self._cache
+        if c is not None and c[0] == seqName and beginPos >= c[1] and endPos < c[2] and endPos >= beginPos:
+            return c[3][beginPos - c[1]:endPos - c[1]]               # fastafile.pyx:148-150
         t = self.refs[seqName]
         beginPos = max(0, beginPos)
         endPos = min(t.SeqLength - 1, endPos)

@@ -14,6 +14,7 @@ follow the reference's rules:
 File formats (BAM, VCF text) are not handled here: reads come in `bamReadBuffer`s, calls go
 out as Python records.
 """
+import functools
 import math
 from itertools import combinations
 
@@ -260,6 +261,16 @@ def binomial(x, size, prob):
                     + (size - x) * math.log(1.0 - prob))
 
 
+@functools.lru_cache(maxsize=1 << 16)
+def _binomialSum(upto, size, prob):
+    """sum of binomial(i, size, prob) for i = 0..upto, in that order (the p-value sums of
+    cpopulation.pyx:367-386); estimated frequencies repeat (0.5, 1.0, ...), so the sums do too"""
+    total = 0
+    for i in range(upto + 1):
+        total += binomial(i, size, prob)
+    return total
+
+
 def homopolymerLength(variant, refFile):
     """chaplotype.pyx:366-402: the longest run touching the variant's position"""
     left = refFile.getSequence(variant.refName, variant.refPos - 20, variant.refPos)
@@ -286,10 +297,10 @@ def siteStatistics(batch, k, variant, freq, refFile, options, minQuals):
     if tc > 0 and nw / float(tc) >= freq / 2.0:                       # cpopulation.pyx:367-373
         ab = 1.0
     else:
-        ab = sum(binomial(i, tc, freq / 2.0) for i in range(_round_half_up(nw) + 1))
+        ab = _binomialSum(_round_half_up(nw), tc, freq / 2.0)
     p = min(0.99, freq)
-    fwd = sum(binomial(i, _round_half_up(wf), p) for i in range(_round_half_up(variant.nFwdReadsWeighted) + 1))
-    rev = sum(binomial(i, _round_half_up(wr), p) for i in range(_round_half_up(variant.nRevReadsWeighted) + 1))
+    fwd = _binomialSum(_round_half_up(variant.nFwdReadsWeighted), _round_half_up(wf), p)
+    rev = _binomialSum(_round_half_up(variant.nRevReadsWeighted), _round_half_up(wr), p)
     out.update(FPV="%1.2e" % fwd, RPV="%1.2e" % rev, ABPV="%1.2e" % ab)
     return out
 
@@ -339,6 +350,7 @@ def callRegion(chrom, start, end, readBuffers, refFile, options=None, variants=N
     per variant, keep the maxVariants variants with the highest posterior) in a batch of their own.
     """
     options = options or Options()
+    refFile.setCacheSequence(chrom, start - 25000, end + 25000)      # variantcaller.pyx:214
     if variants is None:
         variants = candidatesInRegion(chrom, start, end, readBuffers, refFile, options)
     windows = list(WindowGenerator().WindowsAndVariants(chrom, start, end, variants, options))

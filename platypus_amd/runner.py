@@ -10,10 +10,13 @@ processes, here they are dealt to --nGPU x --workersPerGPU processes, each bound
 nothing is exchanged between them.  Inside a chunk reads are buffered --bufferSize bases at a time
 (platypus/variantcaller.pyx:229-233)."""
 import argparse
+import collections
 import multiprocessing
 import os
 import sys
 import tempfile
+import threading
+import time
 
 from platypus_amd import shard
 
@@ -48,14 +51,26 @@ def call_chunks(chunks, args, tmpdir):
     opts = pipeline.Options(**{k: getattr(args, k) for k in vars(pipeline.Options()) if hasattr(args, k)})
     units = [(ch, s, min(s + args.bufferSize, ch[2])) for ch in chunks for s in range(ch[1], ch[2], args.bufferSize)]
 
+    spent = {"fetch": 0.0, "buffers": 0.0, "wait": 0.0, "call": 0.0, "write": 0.0}
+
+    local = threading.local()
+    opened = []
+
     def load(unit):                                       # fetch, inflate, decode, filter and trim: all outside the lock
         (chrom, _, _), s, e = unit
+        if not hasattr(local, "readers"):                 # a file handle per helper thread
+            local.readers = [bamio.BamReader(b) for b in args.bamFiles.split(",")]
+            opened.extend(local.readers)
         bufs = []
-        for r in readers:
+        for r in local.readers:
+            t0 = time.perf_counter()
             reads = r.fetch(chrom, s, e)
             reads["chrom"] = chrom.encode()
+            t1 = time.perf_counter()
             bufs.append(simulate.buffer_of(reads, s, e, minMapQual=opts.minMapQual, maxReads=int(opts.maxReads),
                                            minGoodQualBases=opts.minGoodQualBases, maxBadQualBases=opts.maxBadQualBases))
+            spent["fetch"] += t1 - t0
+            spent["buffers"] += time.perf_counter() - t1
         return bufs
 
     header = "\n".join(vcfout.header(samples, " ".join(sys.argv[1:]))) + "\n"
@@ -64,11 +79,15 @@ def call_chunks(chunks, args, tmpdir):
             with open(os.path.join(tmpdir, "output_temp_" + shard.region_name(ch)), "w") as f:
                 f.write(header)
     n_calls, out, current = 0, None, None
-    with ThreadPoolExecutor(1) as pool:
-        pending = pool.submit(load, units[0]) if units else None
+    ahead = max(1, args.readAhead)
+    with ThreadPoolExecutor(ahead) as pool:
+        pending = collections.deque(pool.submit(load, u) for u in units[:ahead])
         for i, (ch, s, e) in enumerate(units):
-            bufs = pending.result()
-            pending = pool.submit(load, units[i + 1]) if i + 1 < len(units) else None
+            t0 = time.perf_counter()
+            bufs = pending.popleft().result()
+            spent["wait"] += time.perf_counter() - t0
+            if i + ahead < len(units):
+                pending.append(pool.submit(load, units[i + ahead]))
             if ch is not current:
                 if out is not None:
                     out.close()
@@ -78,13 +97,22 @@ def call_chunks(chunks, args, tmpdir):
             chrom = ch[0]
             if sum(b.readCount for b in bufs) > opts.maxReads:            # variantcaller.pyx:84-88
                 continue
-            for c in pipeline.callRegion(chrom.encode(), s, e, bufs, fa, opts):
+            t0 = time.perf_counter()
+            calls = pipeline.callRegion(chrom.encode(), s, e, bufs, fa, opts)
+            t1 = time.perf_counter()
+            for c in calls:
                 out.write(vcfout.record(c, fa) + "\n")
                 n_calls += 1
+            spent["call"] += t1 - t0
+            spent["write"] += time.perf_counter() - t1
     if out is not None:
         out.close()
-    for r in readers:
+    for r in readers + opened:
         r.close()
+    if os.environ.get("PLATYPUS_AMD_TIMINGS"):             # where a worker's time went (helper thread: fetch, buffers)
+        sys.stderr.write("worker %d: %d calls; helper thread: fetch %.2f s, buffers %.2f s; main thread: waiting %.2f s, "
+                         "calling %.2f s, writing %.2f s\n" % (os.getpid(), n_calls, spent["fetch"], spent["buffers"],
+                                                              spent["wait"], spent["call"], spent["write"]))
     return n_calls
 
 
@@ -104,6 +132,8 @@ def main(argv=None):
     ap.add_argument("--workersPerGPU", type=int, default=1,
                     help="host processes per device: the host side (BAM decoding, candidates, windows) dominates the "
                          "run time, so several processes can share one GPU")
+    ap.add_argument("--readAhead", type=int, default=4,
+                    help="buffers prepared ahead of the one being called, each on a helper thread of its own")
     ap.add_argument("--processRegionSize", type=int, default=1000000)
     ap.add_argument("--bufferSize", type=int, default=1000000)
     from platypus_amd import pipeline

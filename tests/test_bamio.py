@@ -1,8 +1,10 @@
 """BAM writing and reading (BGZF blocks, header, records, .bai linear index) round trip, and region fetch
 against a direct selection of the overlapping records."""
 import gzip
+import struct
 
 import numpy as np
+import pytest
 
 from platypus_amd import bamio, simulate
 
@@ -81,3 +83,32 @@ def test_packed_writer_equals_record_by_record_writer(tmp_path):
     back = bamio.BamReader(a).fetch(b"sim", G + 100, G + 5000)
     lo = np.searchsorted(reads["pos"], G + 100 - 101, side="left")
     assert len(back["pos"]) and set(back["pos"]) <= set(reads["pos"][lo:])
+
+
+def test_block_inflation_in_c(tmp_path):
+    """cbam.inflateBlocks: whole blocks are inflated behind the prefix, a cut-off last block stays
+    unconsumed, damage is reported."""
+    import zlib
+    from platypus_amd import cbam
+
+    def block(payload):
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        body = c.compress(payload) + c.flush()
+        return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(body) + 25) + body +
+                struct.pack("<II", zlib.crc32(payload) & 0xffffffff, len(payload)))
+
+    a, b = bytes(range(256)) * 40, b"second block " * 1000
+    raw = block(a) + block(b"") + block(b)
+    u8 = lambda x: np.frombuffer(x, dtype=np.uint8)
+    out, used = cbam.inflateBlocks(u8(raw), u8(b"left over"))
+    assert used == len(raw) and out.tobytes() == b"left over" + a + b
+    out, used = cbam.inflateBlocks(u8(raw[:-5]), u8(b""))
+    assert used == len(block(a)) + len(block(b"")) and out.tobytes() == a
+    out, used = cbam.inflateBlocks(u8(raw[:10]), u8(b"xy"))
+    assert used == 0 and out.tobytes() == b"xy"
+    damaged = bytearray(raw)
+    damaged[40] ^= 0x55
+    with pytest.raises(IOError):
+        cbam.inflateBlocks(u8(bytes(damaged)), u8(b""))
+    with pytest.raises(IOError):
+        cbam.inflateBlocks(u8(b"not a gzip member at all....."), u8(b""))
