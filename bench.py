@@ -246,7 +246,7 @@ def main():
     # ---- file to file (simulated BAM + FASTA -> VCF through the region caller), not part of the metric:
     # the second figure BASELINE.json names, Mbp/min, for ONE process / one GPU -------------------------
     e2e = None
-    if not args.no_e2e and args.workload == "wgs":
+    if world == 1 and not args.no_e2e and args.workload == "wgs":
         try:
             e2e = end_to_end_leg()
         except Exception as e:                             # reported, never hidden
@@ -254,7 +254,7 @@ def main():
 
     # ---- CPU baseline: the reference's own compiled routine on the host cores ---------
     cpu = None
-    if not args.no_cpu:
+    if world == 1 and not args.no_cpu:                       # rank 0 at N = 1 only: the other ranks would wait
         from oracle import pyoracle as po
         cores = min(16, os.cpu_count() or 1)
         kind = "reference" if po.have_ref() else "port"
