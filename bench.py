@@ -68,7 +68,7 @@ def pmc_traffic(n_pairs, read_len):
     return (2.0 * val["FETCH_SIZE"] + val["WRITE_SIZE"]) * 1024.0, os.path.relpath(files[-1], ROOT)
 
 
-def end_to_end_leg(kb=2000, coverage=30, copies=8):
+def end_to_end_leg(kb=2000, coverage=30, copies=32):
     """Simulate kb kilobases at the given coverage (one planted variant per kb, 100-bp reads with true CIGARs),
     lay `copies` repeats of them end to end as one reference (simulating is far slower than calling),
     write BAM + .bai and FASTA + .fai, call them to a VCF with platypus_amd.runner, time the call."""
