@@ -263,6 +263,8 @@ def inflateBlocks(const unsigned char[::1] raw, const unsigned char[::1] prefix)
             k += 4 + (raw[k + 2] | (raw[k + 3] << 8))
         if bsize < 0:
             raise IOError("BGZF block without a BC field")
+        if bsize + 1 < 12 + xlen + 8:
+            raise IOError("corrupt BGZF block")
         if p + bsize + 1 > n:
             break
         memcpy(&isize, &raw[p + bsize + 1 - 4], 4)
