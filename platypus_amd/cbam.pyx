@@ -25,10 +25,13 @@ def parseRecords(const unsigned char[::1] data, int refID, int start, int end):
     cdef Py_ssize_t nrec = 0, nbases = 0, ncigar = 0, q, cap = 4096
     cdef Py_ssize_t* starts = <Py_ssize_t*>malloc(cap * sizeof(Py_ssize_t))
     cdef Py_ssize_t* grown
-    cdef bint oom = starts == NULL
+    cdef bint oom = starts == NULL, corrupt = False
     with nogil:
         while p + 4 <= n and not oom:
             memcpy(&block, &data[p], 4)
+            if block < 32:
+                corrupt = True
+                break
             if p + 4 + block > n:
                 break
             memcpy(&rid, &data[p + 4], 4)
@@ -38,6 +41,9 @@ def parseRecords(const unsigned char[::1] data, int refID, int start, int end):
             memcpy(&lseq, &data[p + 20], 4)
             lname = binmq & 0xff
             ncig = flagnc & 0xffff
+            if lseq < 0 or 32 + lname + 4 * <Py_ssize_t>ncig + ((<Py_ssize_t>lseq + 1) >> 1) + lseq > block:
+                corrupt = True
+                break
             if rid > refID or rid < 0 or (rid == refID and pos >= end):
                 done = True
                 break
@@ -65,6 +71,9 @@ def parseRecords(const unsigned char[::1] data, int refID, int start, int end):
     if oom:
         free(starts)
         raise MemoryError()
+    if corrupt:
+        free(starts)
+        raise IOError("corrupt BAM record at byte %d of the stretch" % p)
     consumed = p
     seq = np.empty(nbases, dtype=np.uint8)
     qual = np.empty(nbases, dtype=np.uint8)

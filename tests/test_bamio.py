@@ -112,3 +112,19 @@ def test_block_inflation_in_c(tmp_path):
         cbam.inflateBlocks(u8(bytes(damaged)), u8(b""))
     with pytest.raises(IOError):
         cbam.inflateBlocks(u8(b"not a gzip member at all....."), u8(b""))
+
+
+def test_corrupt_records_are_reported():
+    from platypus_amd import cbam
+    rec = struct.pack("<iiiIIiiii", 32 + 3 + 4 + 2 + 4, 0, 100, (4681 << 16) | (60 << 8) | 3, (0 << 16) | 1, 4, -1, -1, 0) + \
+        b"r0\x00" + struct.pack("<I", (4 << 4) | 0) + bytes([0x12, 0x48]) + bytes([30, 30, 30, 30])
+    arrays, used, done = cbam.parseRecords(np.frombuffer(rec, dtype=np.uint8), 0, 0, 1000)
+    assert used == len(rec) and arrays["seq"].tobytes() == b"ACGT" and list(arrays["pos"]) == [100]
+    short = bytearray(rec)
+    short[0:4] = struct.pack("<i", 8)                             # a block size no record can have
+    with pytest.raises(IOError):
+        cbam.parseRecords(np.frombuffer(bytes(short), dtype=np.uint8), 0, 0, 1000)
+    long_seq = bytearray(rec)
+    long_seq[20:24] = struct.pack("<i", 4000)                     # sequence longer than its record
+    with pytest.raises(IOError):
+        cbam.parseRecords(np.frombuffer(bytes(long_seq), dtype=np.uint8), 0, 0, 1000)
