@@ -69,7 +69,8 @@ def pmc_traffic(n_pairs, read_len):
 
 
 def end_to_end_leg(kb=2000, coverage=30, copies=32):
-    """Simulate kb kilobases at the given coverage (one planted variant per kb, 100-bp reads with true CIGARs),
+    """Simulate kb kilobases at the given coverage (one planted variant per kb, 150-bp read pairs from 500 +- 50 bp
+    fragments with true CIGARs),
     lay `copies` repeats of them end to end as one reference (simulating is far slower than calling),
     write BAM + .bai and FASTA + .fai, call them to a VCF with platypus_amd.runner, time the call."""
     import shutil
@@ -81,7 +82,7 @@ def end_to_end_leg(kb=2000, coverage=30, copies=32):
     try:
         genome = simulate.random_genome(rng, G)
         truth = simulate.plant_variants(rng, genome, G // 1000, spacing=600)
-        reads = simulate.simulate_reads(rng, genome, truth, coverage=coverage, read_len=100)
+        reads = simulate.simulate_reads(rng, genome, truth, coverage=coverage, read_len=150, paired=True, insert=(500, 50))
         genome, truth, reads = simulate.tile(genome, truth, reads, copies)
         G *= copies
         fa = os.path.join(work, "ref.fa")
@@ -93,7 +94,7 @@ def end_to_end_leg(kb=2000, coverage=30, copies=32):
         bamio.write_bam(bam, [(b"sim", G)], reads, sample="S")
         out = os.path.join(work, "calls.vcf")
         base = ["callVariants", "--bamFiles", bam, "--refFile", fa, "--regions", "sim:1-%d" % (G - 1), "--output", out,
-                "--maxReadLength", "100"]
+                "--maxReadLength", "150"]
         best = {}
         for workers in (1, 8):                               # host processes sharing the one GPU
             extra = [] if workers == 1 else ["--workersPerGPU", str(workers), "--processRegionSize", str(G // workers)]
@@ -109,6 +110,7 @@ def end_to_end_leg(kb=2000, coverage=30, copies=32):
         return {"mbp_per_min": G / 1e6 / (best[1] / 60.0), "seconds": best[1],
                 "mbp_per_min_8_host_processes": G / 1e6 / (best[8] / 60.0), "seconds_8_host_processes": best[8],
                 "genome_kb": kb * copies, "simulated_kb": kb, "repeats": copies, "coverage": coverage,
+                "read_length": 150, "paired": True,
                 "reads": int(len(reads["pos"])), "bam_mb": os.path.getsize(bam) / 1e6, "vcf_records": len(called),
                 "planted_variants": len(truth), "planted_found": sum(p in called for p, r, a, g in truth),
                 "processes": 1, "what": "simulated BAM + .bai and FASTA + .fai -> VCF, platypus_amd.runner"}

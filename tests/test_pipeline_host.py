@@ -177,6 +177,35 @@ def test_simulator_alignments_are_consistent():
     assert len(found) >= len(variants) - 1
 
 
+def test_paired_simulation_is_consistent():
+    """paired mode: mates point at each other, template lengths are +/- the same span, error-free
+    reads give back exactly the planted variants, and (unlike unpaired reads that share a start,
+    cwindow.pyx:104-113) almost no pair is dropped as a duplicate"""
+    rng = np.random.default_rng(4)
+    genome = simulate.random_genome(rng, 20000)
+    variants = simulate.plant_variants(rng, genome, 25)
+    reads = simulate.simulate_reads(rng, genome, variants, coverage=20, read_len=100, error_rate=0.0, paired=True,
+                                    insert=(300, 30))
+    n = len(reads["pos"])
+    assert n % 2 == 0 and (np.diff(reads["pos"]) >= 0).all()
+    fwd = (reads["flag"] & 0x10) == 0
+    assert fwd.sum() == n // 2 and ((reads["flag"] & 0x1) != 0).all()
+    assert (reads["insertSize"][fwd] > 0).all() and (reads["insertSize"][~fwd] < 0).all()
+    assert sorted(reads["insertSize"][fwd]) == sorted(-reads["insertSize"][~fwd])
+    assert sorted(reads["matePos"][fwd]) == sorted(reads["pos"][~fwd]) and sorted(reads["matePos"][~fwd]) == sorted(reads["pos"][fwd])
+    assert abs(np.mean(reads["insertSize"][fwd]) - 300) < 10
+    fa = FastaFile(sequences={b"sim": genome})
+    buf = simulate.buffer_of(reads, 0, 20000)
+    assert buf.readCount >= 0.99 * n
+    gen = VariantCandidateGenerator((b"sim", 0, 20000), fa)
+    gen.addCandidatesFromBuffer(buf)
+    found = {(v.refPos, v.removed, v.added) for v in gen.getCandidates()}
+    assert found <= {(p, r, a) for p, r, a, g in variants} and len(found) >= len(variants) - 1
+    # the tiled form keeps mates consistent
+    g2, t2, r2 = simulate.tile(genome, variants, reads, 2)
+    assert sorted(r2["matePos"][n:]) == sorted(reads["matePos"] + 20000)
+
+
 def test_binomial_statistics():
     """cpopulation.pyx:106-142 against exact values"""
     import math

@@ -4,7 +4,7 @@
     python tools/time_files.py [genome_kb] [coverage] [workdir]
 
 TF_REPEATS=k lays k repeats of the simulated stretch end to end (simulating is much slower than calling);
-TF_ARGS adds runner arguments; TF_PROFILE=path writes a cProfile dump of the second run.
+TF_PAIRED=1 TF_READLEN=150 simulates 150-bp pairs; TF_ARGS adds runner arguments; TF_PROFILE=path writes a cProfile dump of the second run.
 """
 import os
 import sys
@@ -27,7 +27,9 @@ def main():
     t = time.perf_counter()
     genome = simulate.random_genome(rng, G)
     truth = simulate.plant_variants(rng, genome, G // 1000, spacing=600)
-    reads = simulate.simulate_reads(rng, genome, truth, coverage=cov, read_len=100)
+    rlen = int(os.environ.get("TF_READLEN", "100"))
+    reads = simulate.simulate_reads(rng, genome, truth, coverage=cov, read_len=rlen,
+                                    paired=os.environ.get("TF_PAIRED", "0") == "1", insert=(500, 50))
     copies = int(os.environ.get("TF_REPEATS", "1"))
     if copies > 1:
         genome, truth, reads = simulate.tile(genome, truth, reads, copies)
@@ -51,7 +53,7 @@ def main():
             prof.enable()
         t0 = time.perf_counter()
         runner.main(["callVariants", "--bamFiles", bam, "--refFile", fa, "--regions", "sim:1-%d" % (G - 1), "--output", out,
-                     "--maxReadLength", "100"] + extra)
+                     "--maxReadLength", str(rlen)] + extra)
         dt = time.perf_counter() - t0
         if prof is not None:
             prof.disable()
