@@ -47,6 +47,41 @@ def test_planted_variants_are_called_with_their_genotypes():
     calign.closeDevice()
 
 
+def test_overlapping_read_pairs():
+    """pairs from fragments shorter than two reads: the forward read's overlap with its mate is set
+    to quality 0 (cwindow.pyx:136-144), pairs whose fragment is shorter than one read are dropped
+    (cwindow.pyx:92-98); the planted variants are still called with their genotypes"""
+    from platypus_amd import calign, pipeline, simulate
+    from platypus_amd.fastafile import FastaFile
+    rng = np.random.default_rng(17)
+    G = 16000
+    genome = simulate.random_genome(rng, G)
+    truth = simulate.plant_variants(rng, genome, 40)
+    reads = simulate.simulate_reads(rng, genome, truth, coverage=40, read_len=100, error_rate=0.005, paired=True,
+                                    insert=(170, 25))
+    assert ((reads["insertSize"] > 0) & (reads["insertSize"] < 200)).sum() > 0.3 * len(reads["pos"])
+    fa = FastaFile(sequences={b"sim": genome})
+    buf = simulate.buffer_of(reads, 0, G)
+    trimmed = 0
+    for i in range(0, buf.readCount, 7):
+        pos, end, rlen, mapq, rev, quals = buf.readInfo(i)
+        trimmed += (not rev) and quals.endswith(b"\x00" * 10)
+    assert trimmed > 20
+    calls = pipeline.callRegion(b"sim", 0, G, [buf], fa, pipeline.Options(rlen=100))
+    called = {(v.refPos, v.removed, v.added): (c, vi) for c in calls for vi, v in enumerate(c.variants)}
+    missed = [t for t in truth if (t[0], t[1], t[2]) not in called]
+    assert len(missed) <= 1, missed
+    wrong = 0
+    for pos, rem, add, gt in truth:
+        if (pos, rem, add) in called:
+            c, vi = called[(pos, rem, add)]
+            alleles = sorted(c.GT[0].split("/"))
+            wrong += alleles != (["0", str(vi + 1)] if gt == 1 else [str(vi + 1), str(vi + 1)])
+    assert wrong <= 1
+    assert len([k for k in called if k not in {(t[0], t[1], t[2]) for t in truth}]) <= 2
+    calign.closeDevice()
+
+
 def test_two_samples_and_a_crowded_window():
     """two samples with different genotypes; a window with more candidates than maxVariants goes through the
     posterior pre-filter (variantcaller.pyx:142-166)"""
