@@ -182,3 +182,10 @@ def test_command_line_bam_to_vcf(tmp_path):
     assert sum((p + 1) in found for p, r, a, g in truth) >= len(truth) - 1
     assert sum(found[p + 1][6] == "PASS" for p, r, a, g in truth if (p + 1) in found) >= len(truth) - 3
     calign.closeDevice()
+    # the same chunks dealt to two worker processes sharing the GPU, one buffer ahead: the same records
+    out2 = str(tmp_path / "calls2.vcf")
+    rc = runner.main(["callVariants", "--bamFiles", ",".join(bams), "--refFile", str(fa), "--regions", "sim:1-%d" % (G - 1),
+                      "--output", out2, "--processRegionSize", "25000", "--bufferSize", "10000", "--maxReadLength", "100",
+                      "--workersPerGPU", "2", "--readAhead", "1"])
+    assert rc == 0
+    assert [l for l in open(out2).read().splitlines() if not l.startswith("##")] == [l for l in lines if not l.startswith("##")]
