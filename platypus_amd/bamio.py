@@ -90,6 +90,20 @@ class BamReader(object):
     def close(self):
         self.f.close()
 
+    def regionBytes(self, chrom, start, end):
+        """compressed bytes between the linear-index entries of start and end: a cheap measure of
+        how many reads a region holds (None without an index)"""
+        chrom = chrom if isinstance(chrom, bytes) else chrom.encode()
+        if self.linear is None or chrom not in self.refs:
+            return None
+        lin = self.linear[self.refs.index(chrom)]
+        if not len(lin):
+            return 0
+        filled = np.maximum.accumulate(lin)                  # empty windows carry the previous offset
+        a = filled[min(max(start, 0) >> 14, len(lin) - 1)]
+        b = filled[min(max(end, 0) >> 14, len(lin) - 1)]
+        return int((b >> 16) - (a >> 16))
+
     def fetch(self, chrom, start, end):
         """packed records of `chrom` overlapping [start, end) (0-based), in position order"""
         chrom = chrom if isinstance(chrom, bytes) else chrom.encode()

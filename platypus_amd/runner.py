@@ -145,7 +145,17 @@ def main(argv=None):
     chunks = shard.split_regions(parse_regions(args.regions, fa), args.processRegionSize)
     tmpdir = tempfile.mkdtemp(prefix="platypus_amd_")
     n_workers = max(1, args.nGPU) * max(1, args.workersPerGPU)
-    per_rank = shard.assign(chunks, n_workers)
+    weights = None
+    if n_workers > 1:                                       # longest first by the reads a chunk holds, as far as the
+        from platypus_amd import bamio                      # BAM indexes tell (compressed bytes), else by length
+        sizes = []
+        for b in args.bamFiles.split(","):
+            r = bamio.BamReader(b)
+            sizes.append([r.regionBytes(ch[0], ch[1], ch[2]) for ch in chunks])
+            r.close()
+        if all(v is not None for row in sizes for v in row):
+            weights = [sum(row[i] for row in sizes) + 1 for i in range(len(chunks))]
+    per_rank = shard.assign(chunks, n_workers, weights)
     if n_workers <= 1:
         call_chunks(chunks, args, tmpdir)
     else:

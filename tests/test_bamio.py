@@ -128,3 +128,23 @@ def test_corrupt_records_are_reported():
     long_seq[20:24] = struct.pack("<i", 4000)                     # sequence longer than its record
     with pytest.raises(IOError):
         cbam.parseRecords(np.frombuffer(bytes(long_seq), dtype=np.uint8), 0, 0, 1000)
+
+
+def test_region_bytes_follow_coverage(tmp_path):
+    """BamReader.regionBytes: a stretch with three times the reads weighs about three times as much"""
+    from platypus_amd import simulate
+    rng = np.random.default_rng(5)
+    G = 400000
+    genome = simulate.random_genome(rng, G)
+    lo = simulate.simulate_reads(rng, genome[:200000], [], coverage=5, read_len=100)
+    hi = simulate.simulate_reads(rng, genome[200000:], [], coverage=15, read_len=100)
+    hi["pos"] = hi["pos"] + 200000
+    reads = {k: np.concatenate([lo[k], hi[k]]) for k in ("seq", "qual", "pos", "mapq", "flag", "cigar")}
+    reads["off"] = np.concatenate([lo["off"], hi["off"][1:] + lo["off"][-1]])
+    reads["cigarOff"] = np.concatenate([lo["cigarOff"], hi["cigarOff"][1:] + lo["cigarOff"][-1]])
+    path = str(tmp_path / "w.bam")
+    bamio.write_bam(path, [(b"sim", G)], reads)
+    r = bamio.BamReader(path)
+    a, b = r.regionBytes("sim", 0, 196608), r.regionBytes("sim", 212992, 399999)
+    assert a > 0 and 2.2 < b / a < 3.8
+    assert r.regionBytes("nope", 0, 10) is None
