@@ -17,9 +17,10 @@
 //   k_em_init/step/update/calls  the same for few large windows, one launch pair per iteration
 //   k_var_post    posterior of a variant given the haplotypes that carry it
 //
-// Sums over reads run in read order like the reference's; sums over genotypes
-// are regrouped (see k_em), so results agree with the reference to rounding,
-// not bit for bit; every reduction has a fixed shape, so runs are reproducible.
+// Sums of logarithms over reads are taken as the logarithm of a product (see
+// LogProduct); sums over genotypes are regrouped (see k_em).  Results agree
+// with the reference to rounding, not bit for bit; every reduction has a fixed
+// shape, so runs are reproducible.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -98,6 +99,23 @@ __device__ __forceinline__ int window_of_cell(const WinDesc* __restrict__ wins, 
     return lo;
 }
 
+// sum over reads of log(0.5 (l1[r] + l2[r])) as ONE logarithm: the terms' mantissas are multiplied
+// (each factor in [0.5, 1), renormalised every 128 factors), their binary exponents added as
+// integers, and log(m) + e ln 2 taken at the end.  A dozen instructions per read instead of a
+// double-precision log(); the result differs from the reference's sum of logarithms
+// (platypus/cgenotype.pyx:58-61) by a few units in the last place of either.
+struct LogProduct {
+    double m = 1.0;
+    int e = 0, k = 0;
+    __device__ __forceinline__ void mul(double l1, double l2) {
+        const double x = l1 + l2;                       // the factor 0.5 is one off the exponent
+        m *= __builtin_amdgcn_frexp_mant(x);
+        e += __builtin_amdgcn_frexp_exp(x) - 1;
+        if ((++k & 127) == 0) { e += __builtin_amdgcn_frexp_exp(m); m = __builtin_amdgcn_frexp_mant(m); }
+    }
+    __device__ __forceinline__ double log_value() const { return log(m) + (double)e * 0.6931471805599453094; }
+};
+
 __global__ __launch_bounds__(256) void k_fill_u64(unsigned long long* __restrict__ dst, int n, double v)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -105,8 +123,8 @@ __global__ __launch_bounds__(256) void k_fill_u64(unsigned long long* __restrict
 }
 
 // ---------------------------------------------------------------------------
-// k_gl: ll[cell] = sum over the individual's reads, in read order, of
-// log(0.5 (L[a][r] + L[b][r]))  (platypus/cgenotype.pyx:58-61).  One thread per
+// k_gl: ll[cell] = sum over the individual's reads of
+// log(0.5 (L[a][r] + L[b][r]))  (platypus/cgenotype.pyx:58-61), as one logarithm per cell.  One thread per
 // (window, individual, genotype) cell; an individual without reads keeps 0.0
 // and stays out of the window's maximum (platypus/cpopulation.pyx:717-723).
 // win_max[w] must hold ordered_bits(-1e7) on entry (platypus/cpopulation.pyx:696).
@@ -130,8 +148,9 @@ __global__ __launch_bounds__(256) void k_gl(const WinDesc* __restrict__ wins, in
     const int r0 = ioff[W.ioff_base + i], nr = ioff[W.ioff_base + i + 1] - r0;
     const double* l1 = like + W.like_base + (int64_t)a * W.n_reads + r0;
     const double* l2 = like + W.like_base + (int64_t)b * W.n_reads + r0;
-    double s = 0.0;
-    for (int r = 0; r < nr; ++r) s += log(0.5 * (l1[r] + l2[r]));
+    LogProduct lp;
+    for (int r = 0; r < nr; ++r) lp.mul(l1[r], l2[r]);
+    const double s = lp.log_value();
     if (valid) ll[c] = s;
     // one atomic per wavefront when all its cells belong to one window, else one per cell
     const int w0 = __builtin_amdgcn_readfirstlane(w);
@@ -149,8 +168,8 @@ __global__ __launch_bounds__(256) void k_gl(const WinDesc* __restrict__ wins, in
 // in LDS in chunks of reads (row stride odd, so the lanes of a wavefront, which
 // hold consecutive second haplotypes b, fall into different banks), and every
 // thread walks the genotypes g = tid, tid + 256, ... keeping (a, b) by
-// increments.  Reads are added in read order, chunk after chunk (partial sums
-// rest in ll between chunks).  k_gl reads L straight from global memory, with
+// increments.  Reads are taken in read order, chunk after chunk (one logarithm
+// per chunk; partial sums rest in ll between chunks).  k_gl reads L straight from global memory, with
 // every lane of a wavefront on a different cache line; here the reads of L are
 // coalesced once and the 2 x n_gen x n_reads operand fetches hit LDS.
 // ---------------------------------------------------------------------------
@@ -196,8 +215,9 @@ __global__ __launch_bounds__(256) void k_gl_tile(const WinDesc* __restrict__ win
             while (p >= n - a) { p -= n - a; ++a; }
             const double* l1 = gl_lds + a * stride;
             const double* l2 = gl_lds + (a + p) * stride;
-            double s = rc == 0 ? 0.0 : out[g];
-            for (int r = 0; r < cn; ++r) s += log(0.5 * (l1[r] + l2[r]));       // cgenotype.pyx:58-61
+            LogProduct lp;
+            for (int r = 0; r < cn; ++r) lp.mul(l1[r], l2[r]);                  // cgenotype.pyx:58-61
+            const double s = (rc == 0 ? 0.0 : out[g]) + lp.log_value();
             out[g] = s;
             if (rc + cn >= nr) mx = fmax(mx, s);
             p += 256;
@@ -232,6 +252,53 @@ __global__ __launch_bounds__(256) void k_norm(const WinDesc* __restrict__ wins, 
     double* F = full + W.full_base + (int64_t)i * n * n;
     F[(int64_t)a * n + b] = p;
     F[(int64_t)b * n + a] = p;
+}
+
+// ---------------------------------------------------------------------------
+// k_norm_tile: the same for windows with many haplotypes.  A wavefront takes an
+// 8 x 8 tile (a, b) of the upper triangle of one individual's matrix: rows of
+// eight cells are read and written as whole 64-byte segments, and the mirrored
+// elements are written after an exchange between lanes (lane (da, db) hands its
+// value to lane (db, da)), so that they too leave as 64-byte segments; k_norm
+// writes the mirror one element per cache line.
+// Grid: (individuals of all windows, tile rows of the largest window), 256 threads: the four
+// wavefronts of a workgroup share the tiles of one row.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_norm_tile(const WinDesc* __restrict__ wins, int n_win,
+                                                   const unsigned long long* __restrict__ win_max,
+                                                   double* __restrict__ cells, double* __restrict__ full)
+{
+    int lo = 0, hi = n_win - 1;                      // last window with ind_base <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (wins[mid].ind_base <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const WinDesc W = wins[lo];
+    const int n = W.n_hap, T = (n + 7) >> 3;
+    const int lane = threadIdx.x & 63;
+    const int ta = (int)blockIdx.y;                  // a row of tiles per workgroup, its tiles dealt to the wavefronts
+    if (ta >= T) return;
+    const int i = (int)(blockIdx.x - W.ind_base);
+    const int da = lane >> 3, db = lane & 7;
+    const double mx = from_ordered_bits(win_max[lo]);
+    double* F = full + W.full_base + (int64_t)i * n * n;
+    double* C = cells + W.cell_base + (int64_t)i * W.n_gen;
+    for (int tb = ta + (int)(threadIdx.x >> 6); tb < T; tb += 4) {
+        const int a = ta * 8 + da, b = tb * 8 + db;
+        const bool valid = a < n && b < n && a <= b;
+        double p = 0.0;
+        if (valid) {
+            const int64_t c = tri_row_start(a, n) + (b - a);
+            p = exp(C[c] - mx);                                              // cpopulation.pyx:732-734
+            C[c] = p;
+            F[(int64_t)a * n + b] = p;
+        }
+        // mirror: this lane now holds element (a', b') = (ta*8 + db, tb*8 + da) and writes F[b'][a']
+        const int src = db * 8 + da;
+        const double q = __hiloint2double(__shfl(__double2hiint(p), src), __shfl(__double2loint(p), src));
+        const int a2 = ta * 8 + db, b2 = tb * 8 + da;
+        if (a2 < n && b2 < n && a2 < b2) F[(int64_t)b2 * n + a2] = q;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -576,8 +643,17 @@ __global__ __launch_bounds__(256) void k_em_update(const WinDesc* __restrict__ w
     double ch = 0.0;
     for (int k = tid; k < n; k += 256) {
         double t = 0.0;
-        for (int i = 0; i < W.n_ind; ++i)
-            if (io[i + 1] != io[i]) t += sh[(int64_t)i * n + k];             // cpopulation.pyx:869-880, individual order
+        // eight shares are fetched before the first is added (the compiler keeps loads where they
+        // are written, and fifty dependent load-add steps are fifty memory latencies); the
+        // additions stay in individual order
+        for (int i0 = 0; i0 < W.n_ind; i0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = i0 + j < W.n_ind ? sh[(int64_t)(i0 + j) * n + k] : 0.0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (i0 + j < W.n_ind && io[i0 + j + 1] != io[i0 + j]) t += v[j];   // cpopulation.pyx:869-880, individual order
+        }
         const double old = S.f[W.hap_base + k], nf = t / (2 * n_with_data);  // :883
         S.f_prev[W.hap_base + k] = old;
         S.f[W.hap_base + k] = nf;

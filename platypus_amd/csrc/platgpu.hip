@@ -767,8 +767,14 @@ int pg_caller_launch(pg_ctx* c, int max_iters) {
                            c->d_wins.p, c->n_windows, c->d_ioff.p, c->d_like.p, c->d_cells.p, c->d_win_max.p, c->win_cells);
     }
     PG_HIP(c, hipGetLastError());
-    hipLaunchKernelGGL(pg::k_norm, dim3((unsigned)((c->win_cells + 255) / 256)), dim3(256), 0, c->stream,
-                       c->d_wins.p, c->n_windows, c->d_win_max.p, c->d_cells.p, c->d_full.p, c->win_cells);
+    if (tile) {
+        const int T = (c->max_win_haps + 7) / 8;
+        hipLaunchKernelGGL(pg::k_norm_tile, dim3((unsigned)c->win_inds_total, (unsigned)T), dim3(256), 0,
+                           c->stream, c->d_wins.p, c->n_windows, c->d_win_max.p, c->d_cells.p, c->d_full.p);
+    } else {
+        hipLaunchKernelGGL(pg::k_norm, dim3((unsigned)((c->win_cells + 255) / 256)), dim3(256), 0, c->stream,
+                           c->d_wins.p, c->n_windows, c->d_win_max.p, c->d_cells.p, c->d_full.p, c->win_cells);
+    }
     PG_HIP(c, hipGetLastError());
     PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_CALLER_SETUP + 1], c->stream));
     c->ev_valid[PG_K_CALLER_SETUP] = true;
