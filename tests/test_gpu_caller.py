@@ -102,6 +102,14 @@ def test_very_wide_window():
     run_case(n_windows=1, H=600, R=24, n_ind=5, seed=62, indel_frac=0.05, read_len=30, hap_len=120)
 
 
+def test_hundreds_of_reads_per_individual():
+    """the product of an individual's per-read terms leaves the range of a double long before 300 reads:
+    the device keeps mantissa and exponent apart and renormalises every 128 factors (both the per-cell
+    kernel and the tiled one, whose read chunks here are longer than 128)"""
+    run_case(2, 4, 640, 2, seed=31)
+    run_case(1, 26, 520, 2, seed=32)
+
+
 def test_two_haplotypes():
     run_case(n_windows=40, H=2, R=16, n_ind=2, seed=14)
 
