@@ -323,17 +323,18 @@ __global__ __launch_bounds__(256) void k_norm_tile(const WinDesc* __restrict__ w
 // lane's share of f . y.  16 independent loads are in flight per lane (NC column chunks x
 // 16 / NC rows, all loads of a group issued before its sums); every y_k is still summed over
 // the rows in row order.
-template <int NC>
+template <int NC, int INFLIGHT = 16>
 __device__ __forceinline__ double matvec_pass(const double* P, const double* f_src, double* yv,
-                                              int n, int k0, int lane)
+                                              int n, int k0, int lane, int r_begin = 0, int r_end = -1)
 {
-    constexpr int RU = 16 / NC;
+    if (r_end < 0) r_end = n;
+    constexpr int RU = INFLIGHT / NC;
     double y[NC];
     int kk[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) { const int k = k0 + c * 64 + lane; kk[c] = k < n ? k : n - 1; y[c] = 0.0; }
-    int r = 0;
-    for (; r + RU <= n; r += RU) {
+    int r = r_begin;
+    for (; r + RU <= r_end; r += RU) {
         double pv[RU][NC];
 #pragma unroll
         for (int u = 0; u < RU; ++u)
@@ -346,7 +347,7 @@ __device__ __forceinline__ double matvec_pass(const double* P, const double* f_s
             for (int c = 0; c < NC; ++c) y[c] += pv[u][c] * fr;
         }
     }
-    for (; r < n; ++r) {
+    for (; r < r_end; ++r) {
         const double fr = f_src[r];
 #pragma unroll
         for (int c = 0; c < NC; ++c) y[c] += P[(int64_t)r * n + kk[c]] * fr;
@@ -615,10 +616,60 @@ __device__ __forceinline__ void em_individual(const WinDesc* __restrict__ wins, 
     if (lane == 0) { best_gen[W.ind_base + i] = bj; best_val[W.ind_base + i] = bv; }
 }
 
-__global__ __launch_bounds__(256) void k_em_step(const WinDesc* __restrict__ wins, const int32_t* __restrict__ ioff,
+// One EM step for ONE individual per workgroup (grid: window x individual): the wavefronts
+// (four or eight) take an equal share of the matrix rows each and all columns, their partial products are added in
+// wavefront order.  Several times the wavefronts of em_individual<0>, i.e. several times the bytes in
+// flight: the last iterations of a batch, when few windows are still running, are bound by the
+// memory latency of the few wavefronts left, not by bandwidth.
+__global__ __launch_bounds__(512) void k_em_step(const WinDesc* __restrict__ wins, const int32_t* __restrict__ ioff,
                                                  const double* __restrict__ full, EmState S, int n_max)
 {
-    em_individual<0>(wins, ioff, full, S, n_max, nullptr, nullptr);
+    extern __shared__ double em_lds[];
+    __shared__ double s_part[8];
+    const int w = blockIdx.x;
+    if (S.done[w]) return;
+    const WinDesc W = wins[w];
+    const int i = blockIdx.y;
+    if (i >= W.n_ind) return;
+    const int32_t* io = ioff + W.ioff_base;
+    if (io[i + 1] == io[i]) return;                                          // cpopulation.pyx:834-835
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_thr = blockDim.x, n_wav = n_thr >> 6;
+    const int n = W.n_hap;
+    double* f = em_lds;
+    double* yv = em_lds + n_max + (size_t)wave * n_max;
+    const double* f_glob = S.f + W.hap_base;
+    for (int k = tid; k < n; k += n_thr) f[k] = f_glob[k];
+    __syncthreads();
+    const double* P = full + W.full_base + (int64_t)i * n * n;
+    const int rows = (n + n_wav - 1) / n_wav;
+    const int r0 = wave * rows < n ? wave * rows : n, r1 = r0 + rows < n ? r0 + rows : n;
+    for (int k0 = 0; k0 < n; k0 += 256) {
+        const int nc = (n - k0 + 63) >> 6;
+        if (nc >= 4)      matvec_pass<4>(P, f, yv, n, k0, lane, r0, r1);
+        else if (nc == 3) matvec_pass<3>(P, f, yv, n, k0, lane, r0, r1);
+        else if (nc == 2) matvec_pass<2>(P, f, yv, n, k0, lane, r0, r1);
+        else              matvec_pass<1>(P, f, yv, n, k0, lane, r0, r1);
+    }
+    __syncthreads();
+    double part = 0.0;
+    double* y0 = em_lds + n_max;
+    for (int k = tid; k < n; k += n_thr) {
+        double y = y0[k];
+        for (int v = 1; v < n_wav; ++v) y += y0[(size_t)v * n_max + k];      // wavefront order
+        y0[k] = y;                                    // this thread is the only reader of column k
+        part += f[k] * y;
+    }
+    part = wave_sum(part);
+    if (lane == 0) s_part[wave] = part;
+    __syncthreads();
+    double s = s_part[0];                                                    // csrSum, cpopulation.pyx:849
+    for (int v = 1; v < n_wav; ++v) s += s_part[v];
+    double* sh = S.share + S.share_base[w] + (int64_t)i * n;
+    for (int k = tid; k < n; k += n_thr) {
+        const double t = 2.0 * f[k] * y0[k];
+        sh[k] = s > 0.0 ? t / s : t;                                         // cpopulation.pyx:852-854
+    }
 }
 
 __global__ __launch_bounds__(256) void k_em_calls(const WinDesc* __restrict__ wins, const int32_t* __restrict__ ioff,

@@ -793,7 +793,7 @@ int pg_caller_launch(pg_ctx* c, int max_iters) {
     // whole chip works on them; everything else takes one workgroup per window.
     // PG_EM_KERNEL = small | big | multi forces one of them (experiments, tests).
     const char* force = std::getenv("PG_EM_KERNEL");
-    int path = n_max <= 8 ? 0 : (n_max > 64 && c->n_windows <= 256 && c->max_win_inds >= 4 ? 2 : 1);
+    int path = n_max <= 8 ? 0 : (n_max > 64 && c->n_windows <= 256 && c->max_win_inds >= 4 && c->max_win_inds <= 65535 ? 2 : 1);
     if (force && force[0] == 'b') path = 1;
     if (force && force[0] == 'm') path = 2;
     if (force && force[0] == 's' && n_max <= 8) path = 0;
@@ -813,14 +813,16 @@ int pg_caller_launch(pg_ctx* c, int max_iters) {
         S.f = c->d_freq.p; S.f_prev = c->d_fprev.p; S.share = c->d_share.p; S.iters = c->d_em_iters.p;
         S.change = c->d_em_change.p; S.done = c->d_em_done.p; S.active = c->d_em_done.p + c->n_windows;
         S.share_base = c->d_share_base.p;
-        const dim3 grid2(c->n_windows, (c->max_win_inds + 3) / 4);
+        const dim3 grid2(c->n_windows, (c->max_win_inds + 3) / 4);         // genotype calls: four individuals per workgroup
         const size_t lds2 = (size_t)5 * n_max * sizeof(double);
-        PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_em_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
         PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_em_calls), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
         hipLaunchKernelGGL(pg::k_em_init, dim3(c->n_windows), dim3(256), 0, c->stream, c->d_wins.p, c->n_windows, S);
         int32_t active = c->n_windows;
+        const int step_threads = 512;                         // wavefronts per individual: rows of its matrix split between them
+        const size_t lds_step = (size_t)(1 + step_threads / 64) * n_max * sizeof(double);
+        PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_em_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step));
         for (int it = 0; it < max_iters && active > 0; ++it) {
-            hipLaunchKernelGGL(pg::k_em_step, grid2, dim3(256), lds2, c->stream, c->d_wins.p, c->d_ioff.p, c->d_full.p, S, n_max);
+            hipLaunchKernelGGL(pg::k_em_step, dim3(c->n_windows, c->max_win_inds), dim3(step_threads), lds_step, c->stream, c->d_wins.p, c->d_ioff.p, c->d_full.p, S, n_max);
             hipLaunchKernelGGL(pg::k_em_update, dim3(c->n_windows), dim3(256), 0, c->stream, c->d_wins.p, c->d_ioff.p, S, max_iters);
             if ((it & 7) == 7) {                            // every eight iterations: anything left to do?
                 PG_HIP(c, hipMemcpyAsync(&active, S.active, sizeof active, hipMemcpyDeviceToHost, c->stream));
