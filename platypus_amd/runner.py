@@ -38,6 +38,15 @@ def parse_regions(text, fasta):
     return out
 
 
+def sample_names(args):
+    """cpopulation.pyx:98-101: the file name of every BAM, or what --labels matches in its path"""
+    import re
+    files = args.bamFiles.split(",")
+    if args.labels is None:
+        return [x.split("/")[-1] for x in files]
+    return [re.search(args.labels, x).group(0) for x in files]
+
+
 def call_chunks(chunks, args, tmpdir):
     """Calls every chunk of the list into its own temporary file.  The read buffers of the next
     stretch are prepared on a helper thread (file reads, BGZF inflation, record decoding, filtering and
@@ -45,9 +54,9 @@ def call_chunks(chunks, args, tmpdir):
     from concurrent.futures import ThreadPoolExecutor
     from platypus_amd import bamio, pipeline, simulate, vcfout
     from platypus_amd.fastafile import FastaFile
-    fa = FastaFile(args.refFile, args.refFile + ".fai")
+    fa = FastaFile(args.refFile, args.refFile + ".fai", parseNCBI=bool(args.parseNCBI))
     readers = [bamio.BamReader(b) for b in args.bamFiles.split(",")]
-    samples = [r.sample or os.path.basename(r.fileName) for r in readers]
+    samples = sample_names(args)
     opts = pipeline.Options(**{k: getattr(args, k) for k in vars(pipeline.Options()) if hasattr(args, k)})
     units = [(ch, s, min(s + args.bufferSize, ch[2])) for ch in chunks for s in range(ch[1], ch[2], args.bufferSize)]
 
@@ -97,6 +106,10 @@ def call_chunks(chunks, args, tmpdir):
             chrom = ch[0]
             if sum(b.readCount for b in bufs) > opts.maxReads:            # variantcaller.pyx:84-88
                 continue
+            if args.printVarsAndExit:                         # variantcaller.pyx:110-113
+                for v in pipeline.candidatesInRegion(chrom.encode(), s, e, bufs, fa, opts):
+                    print(v)
+                continue
             t0 = time.perf_counter()
             calls = pipeline.callRegion(chrom.encode(), s, e, bufs, fa, opts)
             t1 = time.perf_counter()
@@ -134,14 +147,33 @@ def main(argv=None):
                          "run time, so several processes can share one GPU")
     ap.add_argument("--readAhead", type=int, default=4,
                     help="buffers prepared ahead of the one being called, each on a helper thread of its own")
+    ap.add_argument("--nCPU", type=int, default=None,
+                    help="the reference's option: taken as the total number of host processes when --workersPerGPU is not given")
+    ap.add_argument("--labels", default=None, help="regular expression that extracts a sample name from a BAM path")
+    ap.add_argument("--printVarsAndExit", type=int, default=0, help="print the variant candidates and stop")
+    ap.add_argument("--parseNCBI", type=int, default=0)
+    ap.add_argument("--nIndividuals", "-n", type=int, default=1, help="accepted; the number of BAM files decides")
+    ap.add_argument("--dataType", default="population")
+    ap.add_argument("--verbosity", type=int, default=2)
+    ap.add_argument("--logFileName", default=None)
+    ap.add_argument("--getVariantsFromBAMs", type=int, default=1)
+    for unsupported in ("--source", "--useCortex", "--freqAsPrior"):
+        ap.add_argument(unsupported, default=None, help="not supported by this build")
     ap.add_argument("--processRegionSize", type=int, default=1000000)
     ap.add_argument("--bufferSize", type=int, default=1000000)
     from platypus_amd import pipeline
     for k, v in vars(pipeline.Options()).items():
         ap.add_argument("--" + ("maxReadLength" if k == "rlen" else k), dest=k, type=type(v), default=v)
     args = ap.parse_args(argv)
+    for name in ("source", "useCortex", "freqAsPrior"):
+        if getattr(args, name) not in (None, "0", 0):
+            ap.error("--%s is not supported: candidates come from the BAM files only" % name)
+    if args.ploidy != 2 or args.dataType != "population" or not args.getVariantsFromBAMs:
+        ap.error("only --ploidy 2, --dataType population and --getVariantsFromBAMs 1 are supported")
+    if args.nCPU is not None and "--workersPerGPU" not in (argv if argv is not None else sys.argv):
+        args.workersPerGPU = max(1, -(-args.nCPU // max(1, args.nGPU)))
     from platypus_amd.fastafile import FastaFile
-    fa = FastaFile(args.refFile, args.refFile + ".fai")
+    fa = FastaFile(args.refFile, args.refFile + ".fai", parseNCBI=bool(args.parseNCBI))
     chunks = shard.split_regions(parse_regions(args.regions, fa), args.processRegionSize)
     tmpdir = tempfile.mkdtemp(prefix="platypus_amd_")
     n_workers = max(1, args.nGPU) * max(1, args.workersPerGPU)

@@ -153,7 +153,7 @@ def test_command_line_bam_to_vcf(tmp_path):
     lines = open(out).read().splitlines()
     head = [l for l in lines if l.startswith("#")]
     body = [l.split("\t") for l in lines if not l.startswith("#")]
-    assert head[0] == "##fileformat=VCFv4.0" and head[-1].split("\t")[-2:] == ["S0", "S1"]
+    assert head[0] == "##fileformat=VCFv4.0" and head[-1].split("\t")[-2:] == ["s0.bam", "s1.bam"]    # cpopulation.pyx:98-99: file names
     assert sum(l.startswith("#CHROM") for l in lines) == 1                     # one header after the merge
     pos = [int(b[1]) for b in body]
     assert pos == sorted(pos) and len(body) >= len(truth) - 1
@@ -189,3 +189,34 @@ def test_command_line_bam_to_vcf(tmp_path):
                       "--workersPerGPU", "2", "--readAhead", "1"])
     assert rc == 0
     assert [l for l in open(out2).read().splitlines() if not l.startswith("##")] == [l for l in lines if not l.startswith("##")]
+    # the reference's own spellings: --nCPU for the number of host processes, --labels for sample names
+    out3 = str(tmp_path / "calls3.vcf")
+    rc = runner.main(["callVariants", "--bamFiles", ",".join(bams), "--refFile", str(fa), "--regions", "sim:1-%d" % (G - 1),
+                      "--output", out3, "--processRegionSize", "25000", "--bufferSize", "10000", "--maxReadLength", "100",
+                      "--nCPU", "2", "--labels", "s[0-9]"])
+    assert rc == 0
+    lines3 = open(out3).read().splitlines()
+    assert [l for l in lines3 if l.startswith("#CHROM")][0].split("\t")[-2:] == ["s0", "s1"]
+    assert [l for l in lines3 if not l.startswith("#")] == [l for l in lines if not l.startswith("#")]
+
+
+def test_print_candidates_and_exit(tmp_path, capsys):
+    """--printVarsAndExit 1 (variantcaller.pyx:110-113): the candidate list, no calls"""
+    from platypus_amd import bamio, runner, simulate
+    rng = np.random.default_rng(23)
+    G = 12000
+    genome = simulate.random_genome(rng, G)
+    truth = simulate.plant_variants(rng, genome, 10, spacing=500)
+    fa = tmp_path / "ref.fa"
+    fa.write_bytes(b">sim\n" + b"\n".join(genome[i:i + 60] for i in range(0, G, 60)) + b"\n")
+    (tmp_path / "ref.fa.fai").write_bytes(b"sim\t%d\t5\t60\t61\n" % G)
+    reads = simulate.simulate_reads(rng, genome, truth, coverage=20, read_len=100, error_rate=0.0)
+    bam = str(tmp_path / "s.bam")
+    bamio.write_bam(bam, [(b"sim", G)], reads)
+    out = str(tmp_path / "none.vcf")
+    rc = runner.main(["callVariants", "--bamFiles", bam, "--refFile", str(fa), "--regions", "sim:1-%d" % (G - 1),
+                      "--output", out, "--printVarsAndExit", "1", "--maxReadLength", "100"])
+    assert rc == 0
+    printed = [l for l in capsys.readouterr().out.splitlines() if l.strip()]
+    assert len(truth) - 1 <= len(printed) <= len(truth)
+    assert not [l for l in open(out).read().splitlines() if l and not l.startswith("#")]
