@@ -65,7 +65,11 @@ def main():
     t0 = time.perf_counter()
     n_batches = n_pairs = n_bad = n_assert = n_refused = 0
     mLTOT = -0.23025850929940459
+    last_report = t0
     while time.perf_counter() - t0 < budget:
+        if time.perf_counter() - last_report > 30:             # a line every half minute: the run is alive
+            last_report = time.perf_counter()
+            print("... %d batches, %d pairs, %d with differences so far" % (n_batches, n_pairs, n_bad), flush=True)
         b, (ge, npr, tab) = make(seed)
         try:
             ctx.set_params(ge, npr, tab)
