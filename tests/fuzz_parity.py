@@ -2,7 +2,7 @@
 """Randomised parity run: batches of random shape and content through the C ABI against the CPU
 checker (DP by the reference's compiled routine when oracle/_ref is built), for a time budget.
 
-    python tools/fuzz_parity.py [seconds] [first_seed]
+    python tests/fuzz_parity.py [seconds] [first_seed]
 
 Every batch draws its own window count, haplotypes and reads per window, read length (8..300,
 single or ragged), haplotype length (60..2000), share of indel haplotypes, homopolymer runs, 'N'

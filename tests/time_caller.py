@@ -2,7 +2,7 @@
 """Times the genotype-likelihood / EM stage on the benchmark pair streams (GPU kernels by HIP events,
 the CPU restatement on a sample of windows beside it).
 
-    python tools/time_caller.py [wgs|panel|joint] [windows-of-wgs-shape]
+    python tests/time_caller.py [wgs|panel|joint] [windows-of-wgs-shape]
 """
 import os
 import sys
