@@ -16,6 +16,7 @@ out as Python records.
 """
 import functools
 import math
+import time
 from itertools import combinations
 
 from platypus_amd import chaplotype, cpopulation
@@ -350,9 +351,11 @@ def callRegion(chrom, start, end, readBuffers, refFile, options=None, variants=N
     per variant, keep the maxVariants variants with the highest posterior) in a batch of their own.
     """
     options = options or Options()
+    t_begin = time.perf_counter()
     refFile.setCacheSequence(chrom, start - 25000, end + 25000)      # variantcaller.pyx:214
     if variants is None:
         variants = candidatesInRegion(chrom, start, end, readBuffers, refFile, options)
+    t_cands = time.perf_counter()
     windows = list(WindowGenerator().WindowsAndVariants(chrom, start, end, variants, options))
     refHap = {}
     nReads = {}
@@ -413,7 +416,9 @@ def callRegion(chrom, start, end, readBuffers, refFile, options=None, variants=N
         stats.update(windows=len(windows), called_windows=len(order), candidates=len(variants))
     if not len(batch):
         return []
+    t_collected = time.perf_counter()
     pops = batch.run(options.maxIters)
+    t_ran = time.perf_counter()
     if stats is not None:
         stats.update(batch.timings)
 
@@ -500,4 +505,7 @@ def callRegion(chrom, start, end, readBuffers, refFile, options=None, variants=N
                 if gl is not None and c.GT[ind] != "./.":
                     c.GL[ind] = [round(x, 2) for x in gl]
     calls.sort(key=lambda c: c.pos)
+    if stats is not None:                                         # seconds per phase of this call
+        stats.update(t_candidates=t_cands - t_begin, t_collect=t_collected - t_cands, t_batch=t_ran - t_collected,
+                     t_consume=time.perf_counter() - t_ran)
     return calls

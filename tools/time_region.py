@@ -50,6 +50,9 @@ def main():
                   rep, t1 - t0, t2 - t1, len(cands), t3 - t2, stats.get("pack", 0), stats.get("upload", 0),
                   stats.get("device", 0), stats.get("unpack", 0), total, G / 1e6 / (total / 60.0),
                   stats.get("called_windows", 0), len(calls), hit, len(truth), len(found) - hit), flush=True)
+        print("       phases of the call: candidates %.3f s, windows + haplotypes + collect %.3f s, device batch (pack .. unpack) "
+              "%.3f s, consume %.3f s" % (stats.get("t_candidates", 0), stats.get("t_collect", 0), stats.get("t_batch", 0),
+                                          stats.get("t_consume", 0)), flush=True)
         ms = stats.get("anchor_ms", 0) + stats.get("align_ms", 0)
         print("       device: %d pairs, %.3g cells; anchor %.3f ms + alignment %.3f ms -> %.0f GCUPS on this pair stream; "
               "genotype setup %.3f ms, EM %.3f ms" % (stats.get("pairs", 0), stats.get("cells", 0), stats.get("anchor_ms", 0),
