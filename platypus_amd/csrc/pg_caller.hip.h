@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void k_norm_tile(const WinDesc* __restrict__ w
 // The genotype calls (:773-797) use the csr values of the LAST iteration, i.e.
 // the frequencies before its update; they are recomputed from those at the end.
 // LDS: f, f_prev, f_new [n_max] | per wavefront: y [n_max], acc [n_max] | staged matrices
-// (stage_doubles > 0: every window of the batch has at most that many matrix elements).
+// (a window of at most stage_doubles matrix elements is copied there once and read from LDS in every iteration).
 // ---------------------------------------------------------------------------
 // Columns k0 + c * 64 + lane, c < NC, of y = P f for one wavefront: yv[k] = y_k, returns the
 // lane's share of f . y.  16 independent loads are in flight per lane (NC column chunks x
@@ -498,7 +498,8 @@ __global__ __launch_bounds__(1024) void k_em(const WinDesc* __restrict__ wins,
     extern __shared__ double em_lds[];
     __shared__ double s_red[16];
     __shared__ int s_with_data;
-    if (staged)
+    const WinDesc W0 = wins[blockIdx.x];           // windows whose matrices fit the staging area keep them in LDS
+    if ((int64_t)W0.n_ind * W0.n_hap * W0.n_hap <= (int64_t)staged)
         em_window<true>(em_lds, s_red, &s_with_data, wins, ioff, full, max_iters, n_max,
                         freq_out, iters_out, change_out, best_gen, best_val);
     else

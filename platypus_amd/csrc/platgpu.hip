@@ -783,9 +783,17 @@ int pg_caller_launch(pg_ctx* c, int max_iters) {
     int n_wav = std::max(1, std::min(16, c->max_win_inds));
     while (n_wav > 1 && (size_t)(3 + 2 * n_wav) * n_max * sizeof(double) > 150 * 1024) --n_wav;
     size_t lds = (size_t)(3 + 2 * n_wav) * n_max * sizeof(double);
-    // windows whose matrices all fit in 32 KiB keep them in LDS
+    // windows whose matrices fit in what is left of the LDS (at most 128 KiB) keep them there: every
+    // iteration reads them again, and a window's wavefronts wait on each other's memory latency
     int stage = 0;
-    if (c->max_win_full <= 4096) { stage = (int)c->max_win_full; lds += (size_t)stage * sizeof(double); }
+    {
+        // (with thousands of windows in the batch, most of them small, occupancy matters more: 32 KiB then)
+        int64_t stage_max = c->n_windows > 2048 ? 4096 : 16384;
+        if (const char* k = std::getenv("PG_EM_STAGE_MAX")) stage_max = std::atoll(k);      // experiments
+        const int64_t room = ((int64_t)152 * 1024 - (int64_t)lds) / (int64_t)sizeof(double);   // static LDS and rounding need the rest
+        const int64_t cap = std::min(stage_max, room);
+        if (cap > 0) { stage = (int)std::min<int64_t>(c->max_win_full, cap); lds += (size_t)stage * sizeof(double); }
+    }
     PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_em), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_CALLER_EM], c->stream));
     // Kernel choice: windows of at most 8 haplotypes take one wavefront each; few large windows (more than
