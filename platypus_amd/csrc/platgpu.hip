@@ -796,12 +796,12 @@ int pg_caller_launch(pg_ctx* c, int max_iters) {
     }
     PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_em), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_CALLER_EM], c->stream));
-    // Kernel choice: windows of at most 8 haplotypes take one wavefront each; few large windows (more than
-    // 64 haplotypes, at most 256 windows) with several individuals run one launch pair per iteration over (window, individuals) so that the
-    // whole chip works on them; everything else takes one workgroup per window.
+    // Kernel choice: windows of at most 8 haplotypes take one wavefront each; if every window's matrices fit
+    // the LDS staging area, one workgroup per window iterates on them there; otherwise every iteration is a
+    // launch pair over (window, individual) workgroups, so that the whole chip streams the matrices.
     // PG_EM_KERNEL = small | big | multi forces one of them (experiments, tests).
     const char* force = std::getenv("PG_EM_KERNEL");
-    int path = n_max <= 8 ? 0 : (n_max > 64 && c->n_windows <= 256 && c->max_win_inds >= 4 && c->max_win_inds <= 65535 ? 2 : 1);
+    int path = n_max <= 8 ? 0 : (c->max_win_full > (int64_t)stage && c->max_win_inds <= 65535 ? 2 : 1);
     if (force && force[0] == 'b') path = 1;
     if (force && force[0] == 'm') path = 2;
     if (force && force[0] == 's' && n_max <= 8) path = 0;
@@ -826,7 +826,9 @@ int pg_caller_launch(pg_ctx* c, int max_iters) {
         PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_em_calls), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
         hipLaunchKernelGGL(pg::k_em_init, dim3(c->n_windows), dim3(256), 0, c->stream, c->d_wins.p, c->n_windows, S);
         int32_t active = c->n_windows;
-        const int step_threads = 512;                         // wavefronts per individual: rows of its matrix split between them
+        // wavefronts per individual (the rows of its matrix are split between them): enough to keep loads in
+        // flight for a large matrix, one for a small one
+        const int step_threads = n_max <= 64 ? 64 : (n_max <= 128 ? 256 : 512);
         const size_t lds_step = (size_t)(1 + step_threads / 64) * n_max * sizeof(double);
         PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_em_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step));
         for (int it = 0; it < max_iters && active > 0; ++it) {
