@@ -259,27 +259,28 @@ cdef class WindowBatch:
     def __len__(self):
         return len(self.windows)
 
-    def add(self, list haplotypes, list readBuffers):
-        """Returns the window's index in this batch.  A window without any read is refused
-        (the reference divides by zero there, cpopulation.pyx:883)."""
+    def add(self, list haplotypes, list readBuffers, start=None, end=None):
+        """Returns the window's index in this batch.  The window's reads are the buffers' current window
+        ranges, or those of [start, end) when given (platypus/cwindow.pyx:242-267); they are kept as
+        (first read, count) per buffer.  A window without any read is refused (the reference divides by
+        zero there, cpopulation.pyx:883)."""
         cdef bamReadBuffer buf
         cdef int i, n, tot = 0
         cdef list counts = []
-        cdef list ptrs = []
-        cdef size_t p
-        cdef cAlignedRead** ws
+        cdef list firsts = []
         if len(haplotypes) < 1 or len(haplotypes) > 1000:
             raise ValueError("a window needs 1..1000 haplotypes (cpopulation.pyx:546)")
         for i in range(len(readBuffers)):
             buf = readBuffers[i]
+            if start is not None:
+                buf.setWindowPointers(start, end)
             n = <int>(buf.windowEnd - buf.windowStart)
-            ws = buf.windowStart
             counts.append(n)
-            ptrs.append([<size_t>ws[r] for r in range(n)])
+            firsts.append(<int>(buf.windowStart - buf.cReads))
             tot += n
         if tot == 0:
             raise ValueError("the window has no reads")
-        self.windows.append((haplotypes, readBuffers, counts, ptrs))
+        self.windows.append((haplotypes, readBuffers, counts, firsts))
         return len(self.windows) - 1
 
     def coverage(self, int w, int varPos):
@@ -287,12 +288,13 @@ cdef class WindowBatch:
         span position varPos (pos <= varPos <= end), and how many of them are on the reverse /
         forward strand."""
         cdef cAlignedRead* rd
-        cdef size_t p
-        cdef int tc = 0, tcr = 0
-        for lst in self.windows[w][3]:
-            for q in lst:
-                p = q
-                rd = <cAlignedRead*>p
+        cdef bamReadBuffer buf
+        cdef int tc = 0, tcr = 0, bi, r, lo, n
+        haps, bufs, counts, firsts = self.windows[w]
+        for bi in range(len(bufs)):
+            buf = bufs[bi]; lo = firsts[bi]; n = counts[bi]
+            for r in range(n):
+                rd = buf.cReads[lo + r]
                 if rd.pos <= varPos and rd.end >= varPos:
                     tc += 1
                     if rd.isReverse:
@@ -306,16 +308,17 @@ cdef class WindowBatch:
         single added base there, the smallest quality in a window of badReadsWindow bases around it
         (empty unless `added` is one base, cpopulation.pyx:290-310)."""
         cdef cAlignedRead* rd
-        cdef size_t p
-        cdef int tc = 0, tcr = 0, ws, we, k, mn
+        cdef bamReadBuffer buf
+        cdef int tc = 0, tcr = 0, ws, we, k, mn, bi, r, lo, n
         cdef double wr = 0.0, wf = 0.0
         cdef list mins = []
         cdef bint single = len(added) == 1
         cdef char addedChar = added[0] if single else 0
-        for lst in self.windows[w][3]:
-            for q in lst:
-                p = q
-                rd = <cAlignedRead*>p
+        haps, bufs, counts, firsts = self.windows[w]
+        for bi in range(len(bufs)):
+            buf = bufs[bi]; lo = firsts[bi]; n = counts[bi]
+            for r in range(n):
+                rd = buf.cReads[lo + r]
                 if rd.pos <= varPos and rd.end >= varPos:
                     tc += 1
                     if rd.isReverse:
@@ -339,27 +342,27 @@ cdef class WindowBatch:
 
     def run(self, int maxIters=100):
         cdef pg_ctx* ctx = deviceContext()
-        cdef int nW = len(self.windows), w, h, i, r, n
+        cdef int nW = len(self.windows), w, h, i, r, n, lo, cnt
         cdef int64_t nHapTot = 0, nReadTot = 0, nIndTot = 0, hapBytes = 0, readBytes = 0, nCells = 0
         cdef Haplotype hap
         cdef cAlignedRead* rd
-        cdef size_t p
+        cdef bamReadBuffer buf
         if nW == 0:
             return []
         t0 = time.perf_counter()
         for w in range(nW):
-            haps, bufs, counts, ptrs = self.windows[w]
+            haps, bufs, counts, firsts = self.windows[w]
             nHapTot += len(haps)
             nIndTot += len(bufs)
             nCells += <int64_t>len(bufs) * (len(haps) * (len(haps) + 1) // 2)
             for hp in haps:
                 hap = hp
                 hapBytes += hap.hapLen
-            for lst in ptrs:
-                nReadTot += len(lst)
-                for q in lst:
-                    p = q
-                    readBytes += (<cAlignedRead*>p).rlen
+            for i in range(len(bufs)):
+                buf = bufs[i]; lo = firsts[i]; n = counts[i]
+                nReadTot += n
+                for r in range(n):
+                    readBytes += buf.cReads[lo + r].rlen
         cdef int64_t* hoff = <int64_t*>malloc((nHapTot + 1) * sizeof(int64_t))
         cdef int32_t* hstart = <int32_t*>malloc((nHapTot + 1) * sizeof(int32_t))
         cdef int32_t* hvl = <int32_t*>malloc((nHapTot + 1) * sizeof(int32_t))
@@ -391,7 +394,7 @@ cdef class WindowBatch:
             hoff[0] = 0
             roff[0] = 0
             for w in range(nW):
-                haps, bufs, counts, ptrs = self.windows[w]
+                haps, bufs, counts, firsts = self.windows[w]
                 b_hlo[w] = <int32_t>hi
                 b_nh[w] = len(haps)
                 b_rlo[w] = <int32_t>ri
@@ -406,9 +409,9 @@ cdef class WindowBatch:
                 ioff[oi] = 0
                 n = 0
                 for i in range(len(bufs)):
-                    for q in ptrs[i]:
-                        p = q
-                        rd = <cAlignedRead*>p
+                    buf = bufs[i]; lo = firsts[i]; cnt = counts[i]
+                    for r in range(cnt):
+                        rd = buf.cReads[lo + r]
                         memcpy(sbuf + roff[ri], rd.seq, rd.rlen)
                         memcpy(qbuf + roff[ri], rd.qual, rd.rlen)
                         roff[ri + 1] = roff[ri] + rd.rlen
@@ -446,7 +449,7 @@ cdef class WindowBatch:
                     ri += 1
             hi = 0; ii = 0; ci = 0
             for w in range(nW):
-                haps, bufs, counts, ptrs = self.windows[w]
+                haps, bufs, counts, firsts = self.windows[w]
                 gts = generateAllGenotypesFromHaplotypeList(2, haps)
                 out.append(makePopulation(haps, gts, bufs, len(bufs), nreads + ii, freq + hi, post + ci,
                                           best + ii, val + ii, iters[w], change[w], w))
@@ -474,11 +477,11 @@ cdef class WindowBatch:
         reference rounds to two decimals -- or None for an individual without reads.
         The genotype/EM results of `run` stay valid."""
         cdef pg_ctx* ctx = deviceContext()
-        cdef int nItems = len(items), it, i, w, n, k
+        cdef int nItems = len(items), it, i, w, n, k, bi, r, lo, cnt
         cdef int64_t hapBytes = 0, readBytes = 0, nReadTot = 0, nRows = 0, ri = 0, row = 0
         cdef Haplotype hap
         cdef cAlignedRead* rd
-        cdef size_t p
+        cdef bamReadBuffer buf
         cdef dict readBase = {}
         cdef list order = []
         if nItems == 0:
@@ -493,11 +496,12 @@ cdef class WindowBatch:
             hapBytes += hap.hapLen
             nRows += 3 * len(self.windows[w][1])
         for w in order:
-            for lst in self.windows[w][3]:
-                nReadTot += len(lst)
-                for q in lst:
-                    p = q
-                    readBytes += (<cAlignedRead*>p).rlen
+            haps_w, bufs_w, counts_w, firsts_w = self.windows[w]
+            for bi in range(len(bufs_w)):
+                buf = bufs_w[bi]; lo = firsts_w[bi]; cnt = counts_w[bi]
+                nReadTot += cnt
+                for r in range(cnt):
+                    readBytes += buf.cReads[lo + r].rlen
         cdef int64_t* hoff = <int64_t*>malloc((2 * nItems + 1) * sizeof(int64_t))
         cdef int32_t* hstart = <int32_t*>malloc((2 * nItems + 1) * sizeof(int32_t))
         cdef int32_t* hvl = <int32_t*>malloc((2 * nItems + 1) * sizeof(int32_t))
@@ -522,10 +526,11 @@ cdef class WindowBatch:
             roff[0] = 0
             for w in order:                                       # reads of every window involved, once
                 readBase[w] = ri
-                for lst in self.windows[w][3]:
-                    for q in lst:
-                        p = q
-                        rd = <cAlignedRead*>p
+                haps_w, bufs_w, counts_w, firsts_w = self.windows[w]
+                for bi in range(len(bufs_w)):
+                    buf = bufs_w[bi]; lo = firsts_w[bi]; cnt = counts_w[bi]
+                    for r in range(cnt):
+                        rd = buf.cReads[lo + r]
                         memcpy(sbuf + roff[ri], rd.seq, rd.rlen)
                         memcpy(qbuf + roff[ri], rd.qual, rd.rlen)
                         roff[ri + 1] = roff[ri] + rd.rlen

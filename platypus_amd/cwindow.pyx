@@ -268,3 +268,14 @@ cdef class bamReadBuffer:
     @property
     def readCount(self):
         return self.nReads
+
+
+def windowReadCount(list readBuffers, int start, int end):
+    """points every buffer at the reads of [start, end) (setWindowPointers) and returns their number over all buffers"""
+    cdef bamReadBuffer buf
+    cdef int n = 0
+    for b in readBuffers:
+        buf = b
+        buf.setWindowPointers(start, end)
+        n += <int>(buf.windowEnd - buf.windowStart)
+    return n

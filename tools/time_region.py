@@ -29,6 +29,12 @@ def main():
     reads = [simulate.simulate_reads(rng, genome, truth, coverage=cov, read_len=100, error_rate=err,
                                      error_qual=(5, int(os.environ.get("TR_ERROR_QMAX", "25"))))
              for _ in range(n_samples)]
+    copies = int(os.environ.get("TR_REPEATS", "1"))           # lay repeats of the simulated stretch end to end
+    if copies > 1:
+        tiled = [simulate.tile(genome, truth, r, copies) for r in reads]
+        genome, truth, reads = tiled[0][0], tiled[0][1], [t[2] for t in tiled]
+        G *= copies
+        kb *= copies
     print("simulated %d kb, %d variants, %d x %d reads in %.1f s" % (kb, len(truth), n_samples, len(reads[0]["pos"]),
                                                                       time.perf_counter() - t), flush=True)
     fa = FastaFile(sequences={b"sim": genome})
