@@ -15,7 +15,7 @@ path and are not mirrored.
 """
 from libc.stdint cimport int32_t, int64_t, uint8_t
 from libc.stdlib cimport malloc, calloc, free
-from libc.string cimport memcpy
+from libc.string cimport memcpy, memset
 from libc.math cimport exp
 import time
 
@@ -347,6 +347,12 @@ cdef class WindowBatch:
         cdef Haplotype hap
         cdef cAlignedRead* rd
         cdef bamReadBuffer buf
+        cdef int64_t nInc = 0, nPairs = 0, pi = 0
+        cdef dict slots = {}
+        cdef list slotBufs = []
+        cdef int slot
+        cdef int32_t* m
+        cdef int32_t* maps[4096]
         if nW == 0:
             return []
         t0 = time.perf_counter()
@@ -360,9 +366,23 @@ cdef class WindowBatch:
                 hapBytes += hap.hapLen
             for i in range(len(bufs)):
                 buf = bufs[i]; lo = firsts[i]; n = counts[i]
-                nReadTot += n
+                nInc += n
+                nPairs += <int64_t>len(haps) * n
+                slot = slots.get(id(buf), -1)
+                if slot < 0:                                      # a read that lies in several windows is uploaded once:
+                    slot = len(slotBufs)                          # per buffer, a map from its reads to their place in the batch
+                    slots[id(buf)] = slot
+                    slotBufs.append(buf)
+                    if slot >= 4096:
+                        raise ValueError("more than 4096 read buffers in one batch")
+                    maps[slot] = <int32_t*>malloc((buf.nReads + 1) * sizeof(int32_t))
+                    memset(maps[slot], 0xff, (buf.nReads + 1) * sizeof(int32_t))
+                m = maps[slot]
                 for r in range(n):
-                    readBytes += buf.cReads[lo + r].rlen
+                    if m[lo + r] < 0:
+                        m[lo + r] = 0
+                        nReadTot += 1
+                        readBytes += buf.cReads[lo + r].rlen
         cdef int64_t* hoff = <int64_t*>malloc((nHapTot + 1) * sizeof(int64_t))
         cdef int32_t* hstart = <int32_t*>malloc((nHapTot + 1) * sizeof(int32_t))
         cdef int32_t* hvl = <int32_t*>malloc((nHapTot + 1) * sizeof(int32_t))
@@ -386,19 +406,35 @@ cdef class WindowBatch:
         cdef int32_t* best = <int32_t*>malloc((nIndTot + 1) * sizeof(int32_t))
         cdef double* val = <double*>malloc((nIndTot + 1) * sizeof(double))
         cdef double* post = <double*>malloc((nCells + 1) * sizeof(double))
-        cdef int64_t hi = 0, ri = 0, ii = 0, oi = 0, ci = 0, nPairs = 0, nCellsDP = 0
+        cdef int64_t hi = 0, ri = 0, ii = 0, oi = 0, ci = 0, nCellsDP = 0
+        cdef int32_t* p_hap = <int32_t*>malloc((nPairs + 1) * sizeof(int32_t))
+        cdef int32_t* p_read = <int32_t*>malloc((nPairs + 1) * sizeof(int32_t))
+        cdef int hl
         cdef float kms[5]
         cdef list out = []
         global g_generation
         try:
             hoff[0] = 0
             roff[0] = 0
+            for slot in range(len(slotBufs)):                     # the batch's reads: every buffer's used reads, in buffer order
+                buf = slotBufs[slot]
+                m = maps[slot]
+                for r in range(buf.nReads):
+                    if m[r] >= 0:
+                        rd = buf.cReads[r]
+                        m[r] = <int32_t>ri
+                        memcpy(sbuf + roff[ri], rd.seq, rd.rlen)
+                        memcpy(qbuf + roff[ri], rd.qual, rd.rlen)
+                        roff[ri + 1] = roff[ri] + rd.rlen
+                        rpos[ri] = rd.pos
+                        rmq[ri] = rd.mapq
+                        ri += 1
             for w in range(nW):
                 haps, bufs, counts, firsts = self.windows[w]
                 b_hlo[w] = <int32_t>hi
                 b_nh[w] = len(haps)
-                b_rlo[w] = <int32_t>ri
                 w_ni[w] = len(bufs)
+                base[w] = pi
                 for hp in haps:
                     hap = hp
                     memcpy(hbuf + hoff[hi], hap.cHaplotypeSequence, hap.hapLen)
@@ -409,18 +445,22 @@ cdef class WindowBatch:
                 ioff[oi] = 0
                 n = 0
                 for i in range(len(bufs)):
-                    buf = bufs[i]; lo = firsts[i]; cnt = counts[i]
-                    for r in range(cnt):
-                        rd = buf.cReads[lo + r]
-                        memcpy(sbuf + roff[ri], rd.seq, rd.rlen)
-                        memcpy(qbuf + roff[ri], rd.qual, rd.rlen)
-                        roff[ri + 1] = roff[ri] + rd.rlen
-                        rpos[ri] = rd.pos
-                        rmq[ri] = rd.mapq
-                        ri += 1
                     n += <int>counts[i]
                     ioff[oi + i + 1] = n
                     nreads[ii + i] = <int>counts[i]
+                for i in range(len(bufs)):                        # the first haplotype's pairs: the window's reads by individual
+                    buf = bufs[i]; lo = firsts[i]; cnt = counts[i]
+                    m = maps[<int>slots[id(buf)]]
+                    for r in range(cnt):
+                        p_hap[pi] = b_hlo[w]
+                        p_read[pi] = m[lo + r]
+                        nCellsDP += <int64_t>len(haps) * 16 * (roff[m[lo + r] + 1] - roff[m[lo + r]] + 8)   # align.c:106
+                        pi += 1
+                for hl in range(1, len(haps)):                    # the other haplotypes: the same reads again
+                    for r in range(n):
+                        p_hap[pi] = b_hlo[w] + hl
+                        p_read[pi] = p_read[base[w] + r]
+                        pi += 1
                 oi += len(bufs) + 1
                 ii += len(bufs)
                 b_nr[w] = n
@@ -429,7 +469,7 @@ cdef class WindowBatch:
             t1 = time.perf_counter()
             check(ctx, pg_haps_upload(ctx, <int>nHapTot, hbuf, hoff, hstart, hvl))
             check(ctx, pg_reads_upload(ctx, <int>nReadTot, sbuf, qbuf, roff, rpos, rmq))
-            check(ctx, pg_pairs_blocks(ctx, nW, b_hlo, b_nh, b_rlo, b_nr, base))
+            check(ctx, pg_pairs_upload(ctx, nPairs, p_hap, p_read))
             t2 = time.perf_counter()
             check(ctx, pg_align_launch(ctx))
             g_generation += 1
@@ -440,13 +480,6 @@ cdef class WindowBatch:
             for w in range(5):                                    # anchor, alignment, genotype, setup, EM (platgpu.h)
                 kms[w] = 0.0
                 pg_kernel_time_ms(ctx, w, &kms[w])
-            for w in range(nW):
-                nPairs += <int64_t>b_nh[w] * b_nr[w]
-            ri = 0
-            for w in range(nW):                                   # cells as the reference's loop executes them (align.c:106)
-                for r in range(b_nr[w]):
-                    nCellsDP += <int64_t>b_nh[w] * 16 * (roff[ri + 1] - roff[ri] + 8)
-                    ri += 1
             hi = 0; ii = 0; ci = 0
             for w in range(nW):
                 haps, bufs, counts, firsts = self.windows[w]
@@ -458,11 +491,14 @@ cdef class WindowBatch:
                 ci += <int64_t>len(bufs) * (len(haps) * (len(haps) + 1) // 2)
             t4 = time.perf_counter()
             self.timings = dict(pack=t1 - t0, upload=t2 - t1, device=t3 - t2, unpack=t4 - t3,
-                                windows=nW, haplotypes=int(nHapTot), reads=int(nReadTot), pairs=int(nPairs),
+                                windows=nW, haplotypes=int(nHapTot), reads=int(nReadTot), read_incidences=int(nInc), pairs=int(nPairs),
                                 cells=int(nCellsDP), anchor_ms=kms[0], align_ms=kms[1], setup_ms=kms[3], em_ms=kms[4])
         finally:
             free(hoff); free(hstart); free(hvl); free(hbuf); free(roff); free(rpos); free(rmq); free(sbuf); free(qbuf)
             free(b_hlo); free(b_nh); free(b_rlo); free(b_nr); free(w_ni); free(base); free(ioff); free(nreads)
+            free(p_hap); free(p_read)
+            for slot in range(len(slotBufs)):
+                free(maps[slot])
             free(freq); free(iters); free(change); free(best); free(val); free(post)
         self.populations = out
         return out

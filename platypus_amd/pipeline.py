@@ -437,8 +437,14 @@ def callRegion(chrom, start, end, readBuffers, refFile, options=None, variants=N
     calls, site_items, site_calls = [], [], []
     for k, i in enumerate(order):
         pop = pops[k]
-        freqs = pop.frequenciesPy()
         byPos = {}
+        for v, p in perWin.get(k, []):
+            pp = "%.0f" % (-10.0 * math.log10(max(1e-20, 1.0 - p)))  # cpopulation.pyx:249
+            if float(pp) >= options.minPosterior:                     # variantcaller.pyx:304
+                byPos.setdefault(v.refPos, []).append((v, p, pp))
+        if not byPos:                                                 # nothing of this window is written: no statistics needed
+            continue
+        freqs = pop.frequenciesPy()
         minQuals, stats_list = [], []
         all_vars = {}
         for hap in pop.haplotypes:                                    # INFO and FILTER cover every haplotype's variants
@@ -450,10 +456,6 @@ def callRegion(chrom, start, end, readBuffers, refFile, options=None, variants=N
         win_flags = windowFilters(stats_list, options)
         stats_of = {v: st for v, st in stats_list}
         last_var = stats_list[-1][0] if stats_list else None
-        for v, p in perWin.get(k, []):
-            pp = "%.0f" % (-10.0 * math.log10(max(1e-20, 1.0 - p)))  # cpopulation.pyx:249
-            if float(pp) >= options.minPosterior:                     # variantcaller.pyx:304
-                byPos.setdefault(v.refPos, []).append((v, p, pp))
         for pos in sorted(byPos):
             entries = sorted(byPos[pos], key=lambda t: t[0]._key())
             vs = [e[0] for e in entries]
