@@ -338,7 +338,7 @@ def candidatesInRegion(chrom, start, end, readBuffers, refFile, options):
                                     options.minBaseQual, options.genSNPs, options.genIndels)
     for buf in readBuffers:
         gen.addCandidatesFromBuffer(buf)
-    return filterVariants(gen.getCandidates(), refFile, options.rlen, options.minReads, options.strandFilter,
+    return filterVariants(gen.getCandidates(options.minReads), refFile, options.rlen, options.minReads, options.strandFilter,
                           options.maxSize)
 
 

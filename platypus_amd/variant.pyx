@@ -3,6 +3,8 @@
 sequence, support counters, prior.  Candidate generation from CIGAR strings
 (variant.pyx:253-615) is upstream of the alignment path and not part of this package."""
 from libc.math cimport exp, sqrt
+from libc.stdint cimport int32_t
+from libc.stdlib cimport calloc, malloc, realloc, free
 
 cdef double mLTOT = -0.23025850929940459    # minus log ten over ten
 
@@ -108,6 +110,11 @@ from platypus_amd.samtoolsWrapper cimport cAlignedRead
 from platypus_amd.cwindow cimport bamReadBuffer
 
 
+cdef struct SnpSums:
+    int32_t slot, n, fwd
+    double sumSq, fwdW, revW
+
+
 cdef class VariantCandidateGenerator:
     """Variant candidates from the CIGAR strings and mismatches of buffered reads
     (platypus/variant.pyx:253-615): insertions and deletions flanked by a match of at least
@@ -121,6 +128,16 @@ cdef class VariantCandidateGenerator:
     cdef int refSeqStart
     cdef int refSeqEnd
     cdef int minMapQual, minBaseQual, minFlank, genSNPs, genIndels
+    # single-base mismatches are by far the most frequent candidate: their support is summed in
+    # arrays over (reference position, alternative base) instead of one Variant object per mismatch
+    # (an index per slot into a compact, growing list of sums: the memory touched stays small)
+    cdef int nRef
+    cdef int32_t* snpIndex
+    cdef SnpSums* snpSums
+    cdef int nSnpSums, capSnpSums
+
+    def __dealloc__(self):
+        free(self.snpIndex); free(self.snpSums)
 
     def __init__(self, tuple region, refFile, int minMapQual=20, int minFlank=3, int minBaseQual=20,
                  int genSNPs=1, int genIndels=1):
@@ -131,6 +148,13 @@ cdef class VariantCandidateGenerator:
         self.refSeqEnd = min(region[2] + 2000, refFile.refs[region[0]].SeqLength)
         self.pyRefSeq = refFile.getSequence(self.rname, self.refSeqStart, self.refSeqEnd)
         self.refSeq = self.pyRefSeq
+        self.nRef = <int>len(self.pyRefSeq)
+        self.snpIndex = <int32_t*>calloc(4 * <size_t>self.nRef + 4, sizeof(int32_t))
+        self.capSnpSums = 4096
+        self.nSnpSums = 0
+        self.snpSums = <SnpSums*>malloc(self.capSnpSums * sizeof(SnpSums))
+        if not (self.snpIndex and self.snpSums):
+            raise MemoryError()
         self.minMapQual = minMapQual
         self.minBaseQual = minBaseQual
         self.minFlank = minFlank
@@ -147,8 +171,11 @@ cdef class VariantCandidateGenerator:
     cdef getSnpCandidatesFromReadSegment(self, cAlignedRead* read, int readStart, int readOffset, int refOffset,
                                          int lenSeqToCheck):
         """variant.pyx:309-365"""
-        cdef int index, readIndex, refIndex, baseQual
-        cdef int nRef = <int>len(self.pyRefSeq)
+        cdef int index, readIndex, refIndex, baseQual, alt, k
+        cdef size_t slot
+        cdef SnpSums* acc
+        cdef SnpSums* grown
+        cdef int nRef = self.nRef
         cdef char readChar, refChar
         for index in range(lenSeqToCheck):
             readIndex = index + readOffset
@@ -159,9 +186,36 @@ cdef class VariantCandidateGenerator:
             refChar = self.refSeq[refIndex]
             baseQual = read.qual[readIndex]
             if readChar != refChar and readChar != b'N' and refChar != b'N' and baseQual >= self.minBaseQual:
-                self.addVariantToList(Variant(self.rname, refIndex + self.refSeqStart, bytes([refChar]),
-                                              bytes([readChar]), 1, 0 if read.isReverse else 1, read.mapq,
-                                              baseQual, readIndex + 1))
+                alt = 0 if readChar == b'A' else (1 if readChar == b'C' else (2 if readChar == b'G' else
+                                                                                   (3 if readChar == b'T' else -1)))
+                if alt < 0:                                # another letter: the general path
+                    self.addVariantToList(Variant(self.rname, refIndex + self.refSeqStart, bytes([refChar]),
+                                                  bytes([readChar]), 1, 0 if read.isReverse else 1, read.mapq,
+                                                  baseQual, readIndex + 1))
+                    continue
+                # the sums of Variant.__init__ + addVariant (variant.pyx:57-76,107-119), in read order
+                slot = 4 * <size_t>refIndex + alt
+                k = self.snpIndex[slot] - 1
+                if k < 0:
+                    if self.nSnpSums == self.capSnpSums:
+                        grown = <SnpSums*>realloc(self.snpSums, 2 * <size_t>self.capSnpSums * sizeof(SnpSums))
+                        if grown == NULL:
+                            raise MemoryError()
+                        self.snpSums = grown
+                        self.capSnpSums *= 2
+                    k = self.nSnpSums
+                    self.nSnpSums += 1
+                    self.snpIndex[slot] = k + 1
+                    acc = &self.snpSums[k]
+                    acc.slot = <int32_t>slot; acc.n = 0; acc.fwd = 0; acc.sumSq = 0.0; acc.fwdW = 0.0; acc.revW = 0.0
+                acc = &self.snpSums[k]
+                acc.n += 1
+                acc.sumSq += <double>(readIndex + 1) * (readIndex + 1)
+                if read.isReverse:
+                    acc.revW += 1.0 - exp(mLTOT * baseQual)
+                else:
+                    acc.fwd += 1
+                    acc.fwdW += 1.0 - exp(mLTOT * baseQual)
 
     cdef getVariantCandidatesFromSingleRead(self, cAlignedRead* read):
         """variant.pyx:367-474"""
@@ -209,5 +263,26 @@ cdef class VariantCandidateGenerator:
         for i in range(buf.nReads):
             self.getVariantCandidatesFromSingleRead(buf.cReads[i])
 
-    def getCandidates(self):
+    def getCandidates(self, int minSnpSupport=0):
+        """all candidates, sorted.  minSnpSupport > 0 leaves out single-base mismatches seen in fewer reads:
+        the filter that follows (variantFilter.pyx:12-83) drops them by the same count, and no other
+        candidate can merge with them, so the filtered list is the same and far shorter to sort"""
+        cdef size_t slot
+        cdef Variant v
+        cdef int k
+        cdef SnpSums* acc
+        for k in range(self.nSnpSums):
+            acc = &self.snpSums[k]
+            slot = <size_t>acc.slot
+            self.snpIndex[slot] = 0                        # handed over: a second call does not count them twice
+            if acc.n < minSnpSupport:
+                continue
+            v = Variant(self.rname, <int>(slot >> 2) + self.refSeqStart, bytes([self.refSeq[slot >> 2]]),
+                        b"ACGT"[slot & 3:(slot & 3) + 1], acc.n, acc.fwd, 0, 0, 0)
+            v.sumSqReadPos = acc.sumSq
+            v.rmsReadPos = sqrt(v.sumSqReadPos / acc.n)
+            v.nFwdReadsWeighted = acc.fwdW
+            v.nRevReadsWeighted = acc.revW
+            self.addVariantToList(v)
+        self.nSnpSums = 0
         return sorted(self.variantHeap.values())

@@ -2,6 +2,8 @@
 generation (variant.pyx:253-615), standard form and filtering of candidates (chaplotype.pyx:532-665,
 variantFilter.pyx:12-83), windows (window.py), haplotype enumeration (cfilter.pyx:22-78).  Expectations
 are worked out from the reference's rules by hand or by construction of the simulated data."""
+import math
+
 import numpy as np
 import pytest
 
@@ -90,6 +92,11 @@ def test_candidates_from_cigars():
     by = {(v.refPos, v.removed, v.added): v for v in cands}
     snp = by[(210, ref[210:211], bytes([snp_alt]))]
     assert (snp.nSupportingReads, snp.nFwdReads, snp.nRevReads) == (2, 1, 1)
+    # the sums of variant.pyx:57-76,107-119 over the two reads: weights from the base quality (30), read positions 11 and 10
+    w = 1.0 - math.exp(-0.23025850929940459 * 30)
+    assert snp.nFwdReadsWeighted == w and snp.nRevReadsWeighted == w
+    assert snp.rmsReadPos == math.sqrt((11.0 * 11.0 + 10.0 * 10.0) / 2) and (snp.minPos, snp.maxPos) == (210, 210)
+    assert gen.getCandidates() == cands and gen.getCandidates()[1].nSupportingReads == cands[1].nSupportingReads   # no double counting
     ins_seq = b"TTT" if ref[235:236] != b"T" else b"GGG"
     ins = by[(234, b"", ins_seq)]
     assert (ins.nSupportingReads, ins.nFwdReads, ins.nRevReads) == (2, 1, 1)
@@ -175,6 +182,26 @@ def test_simulator_alignments_are_consistent():
     # error-free reads: every candidate is a planted variant, and every planted variant with coverage is found
     assert found <= {(p, r, a) for p, r, a, g in variants}
     assert len(found) >= len(variants) - 1
+
+
+def test_early_snp_support_cut_changes_nothing():
+    """getCandidates(minSnpSupport) followed by the filter == the filter over all candidates"""
+    rng = np.random.default_rng(8)
+    genome = simulate.random_genome(rng, 30000)
+    variants = simulate.plant_variants(rng, genome, 30)
+    reads = simulate.simulate_reads(rng, genome, variants, coverage=40, read_len=100, error_rate=0.02, error_qual=(15, 41))
+    fa = FastaFile(sequences={b"sim": genome})
+    buf = simulate.buffer_of(reads, 0, 30000)
+    lists = []
+    for cut in (0, 2):
+        gen = VariantCandidateGenerator((b"sim", 0, 30000), fa)
+        gen.addCandidatesFromBuffer(buf)
+        raw = gen.getCandidates(cut)
+        kept = pipeline.filterVariants(raw, fa, 100, 2, 0, 250)
+        lists.append((len(raw), [(v.refPos, v.removed, v.added, v.nSupportingReads, v.nFwdReads, v.nFwdReadsWeighted,
+                                  v.nRevReadsWeighted, v.rmsReadPos) for v in kept]))
+    assert lists[0][1] == lists[1][1] and len(lists[0][1]) > 100
+    assert lists[1][0] < lists[0][0] // 3                     # most single-read mismatches never became objects
 
 
 def test_paired_simulation_is_consistent():
