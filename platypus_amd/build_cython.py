@@ -46,7 +46,7 @@ def build(force=False, verbose=True):
         cc = ["gcc", "-O3", "-fPIC", "-shared", "-fno-strict-aliasing", "-Wno-unused-function",
               "-DNPY_NO_DEPRECATED_API=NPY_1_7_API_VERSION"] + ["-I" + i for i in inc] + \
              ["-o", _ext_path(mod), c_file, "-L" + os.path.join(HERE, "lib"), "-lplatgpu",
-              "-Wl,-rpath,$ORIGIN/lib", "-lm"] + (["-lz"] if mod == "cbam" else [])
+              "-Wl,-rpath,$ORIGIN/lib", "-lm"] + (["-lz", "-ldl"] if mod == "cbam" else [])
         if verbose:
             print(" ".join(cc), flush=True)
         subprocess.check_call(cc)

@@ -249,6 +249,46 @@ cdef extern from "zlib.h":
         Z_FINISH
 
 
+cdef extern from "dlfcn.h":
+    void* dlopen(const char* name, int flags) nogil
+    void* dlsym(void* handle, const char* symbol) nogil
+    enum:
+        RTLD_NOW
+
+# libdeflate inflates BGZF blocks two to three times as fast as zlib.  It is looked up at run time
+# (the image ships the library without its header); zlib is used when it is not there.
+ctypedef void* (*ld_alloc_t)() noexcept nogil
+ctypedef int (*ld_inflate_t)(void* d, const void* src, size_t n_src, void* dst, size_t n_dst, size_t* n_out) noexcept nogil
+ctypedef void (*ld_free_t)(void* d) noexcept nogil
+cdef ld_alloc_t ld_alloc = NULL
+cdef ld_inflate_t ld_inflate = NULL
+cdef ld_free_t ld_free = NULL
+
+
+cdef void find_libdeflate():
+    global ld_alloc, ld_inflate, ld_free
+    cdef void* h = dlopen(b"libdeflate.so.0", RTLD_NOW)
+    if h == NULL:
+        return
+    cdef void* a = dlsym(h, b"libdeflate_alloc_decompressor")
+    cdef void* f = dlsym(h, b"libdeflate_deflate_decompress")
+    cdef void* r = dlsym(h, b"libdeflate_free_decompressor")
+    if a != NULL and f != NULL and r != NULL:
+        ld_alloc = <ld_alloc_t>a
+        ld_inflate = <ld_inflate_t>f
+        ld_free = <ld_free_t>r
+
+
+import os as _os
+if not _os.environ.get("PLATYPUS_AMD_ZLIB_ONLY"):
+    find_libdeflate()
+
+
+def inflateLibrary():
+    """which library inflateBlocks uses"""
+    return "libdeflate" if ld_inflate != NULL else "zlib"
+
+
 def inflateBlocks(const unsigned char[::1] raw, const unsigned char[::1] prefix):
     """Every complete BGZF block at the start of `raw`, inflated one after the other behind a copy of
     `prefix` (what the caller had left over), in one call that does not hold the interpreter lock.
@@ -288,7 +328,35 @@ def inflateBlocks(const unsigned char[::1] raw, const unsigned char[::1] prefix)
         memcpy(&vo[0], &prefix[0], prefix.shape[0])
     if nblocks == 0:
         return out, consumed
-    with nogil:
+    cdef void* dec = NULL
+    cdef size_t got = 0
+    if ld_inflate != NULL:
+        with nogil:
+            dec = ld_alloc()
+            if dec == NULL:
+                bad = 1
+            else:
+                p = 0
+                at = prefix.shape[0]
+                for k in range(nblocks):
+                    xlen = raw[p + 10] | (raw[p + 11] << 8)
+                    bsize = -1
+                    q = p + 12
+                    while q + 4 <= p + 12 + xlen:
+                        if raw[q] == 66 and raw[q + 1] == 67:
+                            bsize = raw[q + 4] | (raw[q + 5] << 8)
+                        q += 4 + (raw[q + 2] | (raw[q + 3] << 8))
+                    memcpy(&isize, &raw[p + bsize + 1 - 4], 4)
+                    if isize:
+                        rc = ld_inflate(dec, &raw[p + 12 + xlen], <size_t>(bsize + 1 - 12 - xlen - 8), &vo[at], isize, &got)
+                        if rc != 0 or got != isize:
+                            bad = 2
+                            break
+                    at += isize
+                    p += bsize + 1
+                ld_free(dec)
+    else:
+      with nogil:
         zs.zalloc = NULL; zs.zfree = NULL; zs.opaque = NULL
         zs.next_in = NULL; zs.avail_in = 0
         if inflateInit2(&zs, -15) != Z_OK:
