@@ -73,7 +73,10 @@ def call_chunks(chunks, args, tmpdir):
         bufs = []
         for r in local.readers:
             t0 = time.perf_counter()
-            reads = r.fetch(chrom, s, e)
+            try:
+                reads = r.fetch(chrom, s, e)
+            except KeyError:                              # this BAM has no such sequence: no reads from it
+                reads = bamio._concat([])
             reads["chrom"] = chrom.encode()
             t1 = time.perf_counter()
             bufs.append(simulate.buffer_of(reads, s, e, minMapQual=opts.minMapQual, maxReads=int(opts.maxReads),
