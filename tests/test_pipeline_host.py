@@ -247,3 +247,16 @@ def test_binomial_statistics():
     assert pipeline.homopolymerLength(Variant(b"c", t0 - 1, b"", b"T"), fa) == 6            # G | TTTTTT
     assert pipeline.homopolymerLength(Variant(b"c", t0 + 2, b"T", b"A"), fa) == 5           # TT [T] TTT: 2 + 3
     assert pipeline.homopolymerLength(Variant(b"c", 100, b"A", b"C"), fa) >= 1
+
+
+def test_region_without_reads_gives_no_calls():
+    """nothing to call, and nothing is asked of the device (this runs without one)"""
+    from platypus_amd import bamio
+    rng = np.random.default_rng(1)
+    genome = simulate.random_genome(rng, 5000)
+    fa = FastaFile(sequences={b"sim": genome})
+    reads = bamio._concat([])
+    reads["chrom"] = b"sim"
+    buf = simulate.buffer_of(reads, 0, 5000)
+    assert buf.readCount == 0
+    assert pipeline.callRegion(b"sim", 0, 5000, [buf], fa, pipeline.Options(rlen=100)) == []
