@@ -89,6 +89,8 @@ cdef class Population:
         return [self.frequencies[i] for i in range(self.nHaplotypes)]
 
     def genotypePosteriorsPy(self):
+        if self.nIndividuals > 0 and self.genotypePosteriors[0] == NULL:
+            raise ValueError("the genotype posteriors of this batch were left on the device (keepPosteriors=False)")
         return [[self.genotypePosteriors[i][g] for g in range(self.nGenotypes)] for i in range(self.nIndividuals)]
 
     def haplotypeIndexesPy(self):
@@ -221,8 +223,9 @@ cdef Population makePopulation(list haplotypes, list genotypes, list readBuffers
     pop.genotypeLikelihoods = []
     for i in range(nI):
         pop.nReads[i] = nReads[i]
-        pop.genotypePosteriors[i] = <double*>malloc(nG * sizeof(double))
-        memcpy(pop.genotypePosteriors[i], post + <size_t>i * nG, nG * sizeof(double))
+        if post != NULL:
+            pop.genotypePosteriors[i] = <double*>malloc(nG * sizeof(double))
+            memcpy(pop.genotypePosteriors[i], post + <size_t>i * nG, nG * sizeof(double))
         if best[i] < 0:                                   # cpopulation.pyx:777-780
             pop.genotypeCalls.append(None)
             pop.genotypeLikelihoods.append(0.0)
@@ -340,7 +343,10 @@ cdef class WindowBatch:
         """reads per individual of window w"""
         return list(self.windows[w][2])
 
-    def run(self, int maxIters=100):
+    def run(self, int maxIters=100, bint keepPosteriors=True):
+        """One alignment launch and one genotype/EM launch for all windows added so far; returns their Populations.
+        keepPosteriors=False leaves the genotype posteriors on the device (variant posteriors and genotype calls
+        are computed there anyway): a caller that only needs calls saves the largest transfer of the batch."""
         cdef pg_ctx* ctx = deviceContext()
         cdef int nW = len(self.windows), w, h, i, r, n, lo, cnt
         cdef int64_t nHapTot = 0, nReadTot = 0, nIndTot = 0, hapBytes = 0, readBytes = 0, nCells = 0
@@ -405,7 +411,7 @@ cdef class WindowBatch:
         cdef double* change = <double*>malloc((nW + 1) * sizeof(double))
         cdef int32_t* best = <int32_t*>malloc((nIndTot + 1) * sizeof(int32_t))
         cdef double* val = <double*>malloc((nIndTot + 1) * sizeof(double))
-        cdef double* post = <double*>malloc((nCells + 1) * sizeof(double))
+        cdef double* post = <double*>malloc(((nCells if keepPosteriors else 0) + 1) * sizeof(double))
         cdef int64_t hi = 0, ri = 0, ii = 0, oi = 0, ci = 0, nCellsDP = 0
         cdef int32_t* p_hap = <int32_t*>malloc((nPairs + 1) * sizeof(int32_t))
         cdef int32_t* p_read = <int32_t*>malloc((nPairs + 1) * sizeof(int32_t))
@@ -475,7 +481,7 @@ cdef class WindowBatch:
             g_generation += 1
             check(ctx, pg_windows_upload(ctx, nW, b_nh, w_ni, base, ioff))
             check(ctx, pg_caller_launch(ctx, maxIters))
-            check(ctx, pg_caller_fetch(ctx, freq, iters, change, best, val, post))
+            check(ctx, pg_caller_fetch(ctx, freq, iters, change, best, val, post if keepPosteriors else NULL))
             t3 = time.perf_counter()
             for w in range(5):                                    # anchor, alignment, genotype, setup, EM (platgpu.h)
                 kms[w] = 0.0
@@ -484,7 +490,7 @@ cdef class WindowBatch:
             for w in range(nW):
                 haps, bufs, counts, firsts = self.windows[w]
                 gts = generateAllGenotypesFromHaplotypeList(2, haps)
-                out.append(makePopulation(haps, gts, bufs, len(bufs), nreads + ii, freq + hi, post + ci,
+                out.append(makePopulation(haps, gts, bufs, len(bufs), nreads + ii, freq + hi, post + ci if keepPosteriors else NULL,
                                           best + ii, val + ii, iters[w], change[w], w))
                 hi += len(haps)
                 ii += len(bufs)

@@ -379,7 +379,7 @@ def callRegion(chrom, start, end, readBuffers, refFile, options=None, variants=N
             pre.add(haps, readBuffers, w["startPos"], w["endPos"])
             pre_ids.append((i, vs))
     if len(pre):
-        pre.run(options.maxIters)
+        pre.run(options.maxIters, keepPosteriors=False)
         post = pre.posteriors([(k, v) for k, (i, vs) in enumerate(pre_ids) for v in vs])
         at = 0
         for k, (i, vs) in enumerate(pre_ids):
@@ -412,7 +412,7 @@ def callRegion(chrom, start, end, readBuffers, refFile, options=None, variants=N
     if not len(batch):
         return []
     t_collected = time.perf_counter()
-    pops = batch.run(options.maxIters)
+    pops = batch.run(options.maxIters, keepPosteriors=False)
     t_ran = time.perf_counter()
     if stats is not None:
         stats.update(batch.timings)
