@@ -43,6 +43,8 @@ struct pg_ctx {
     int max_read_len = 512;
     hipStream_t stream = nullptr;
     hipEvent_t ev[2 * PG_K_COUNT] = {};
+    hipEvent_t ev_block[2] = {};         // EM launch-pair path: one per block of iterations in flight
+    int32_t* h_active = nullptr;         // pinned: windows still running after each block
     bool ev_valid[PG_K_COUNT] = {};
     std::string err;
 
@@ -198,6 +200,8 @@ int pg_ctx_create(int device_ordinal, int max_read_len, pg_ctx** out) {
     }
     for (auto& e : c->ev)
         if (hipEventCreate(&e) != hipSuccess) { delete c; return fail(nullptr, PG_ERR_HIP, "hipEventCreate failed"); }
+    for (auto& e : c->ev_block)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete c; return fail(nullptr, PG_ERR_HIP, "hipEventCreate failed"); }
     int rc = upload_params(c);
     if (rc != PG_OK) { g_create_error = c->err; delete c; return rc; }
     *out = c;
@@ -224,6 +228,8 @@ int pg_ctx_destroy(pg_ctx* c) {
     c->d_best_val.release(); c->d_var_prior.release(); c->d_var_out.release(); c->d_var_moff.release(); c->d_win_max.release(); c->d_fprev.release(); c->d_share.release(); c->d_em_done.release(); c->d_share_base.release(); c->d_rows.release(); c->d_cmp_bytes.release(); c->d_cmp_ints.release(); c->d_var_mask.release(); c->d_vh_recs.release(); c->d_waves.release(); c->d_score.release(); c->d_anchor.release(); c->d_like.release();
     c->d_g1.release(); c->d_g2.release(); c->d_gn.release(); c->d_gout.release();
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->ev_block) if (e) (void)hipEventDestroy(e);
+    if (c->h_active) (void)hipHostFree(c->h_active);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return PG_OK;
@@ -831,14 +837,26 @@ int pg_caller_launch(pg_ctx* c, int max_iters) {
         const int step_threads = n_max <= 64 ? 64 : (n_max <= 128 ? 256 : 512);
         const size_t lds_step = (size_t)(1 + step_threads / 64) * n_max * sizeof(double);
         PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_em_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step));
-        for (int it = 0; it < max_iters && active > 0; ++it) {
-            hipLaunchKernelGGL(pg::k_em_step, dim3(c->n_windows, c->max_win_inds), dim3(step_threads), lds_step, c->stream, c->d_wins.p, c->d_ioff.p, c->d_full.p, S, n_max);
-            hipLaunchKernelGGL(pg::k_em_update, dim3(c->n_windows), dim3(256), 0, c->stream, c->d_wins.p, c->d_ioff.p, S, max_iters);
-            if ((it & 7) == 7) {                            // every eight iterations: anything left to do?
-                PG_HIP(c, hipMemcpyAsync(&active, S.active, sizeof active, hipMemcpyDeviceToHost, c->stream));
-                PG_HIP(c, hipStreamSynchronize(c->stream));
+        // Blocks of eight iterations.  After every block the number of windows still running is copied to
+        // pinned host memory; the host reads the answer of block b only after it has queued block b + 1, so the
+        // device never waits for the host (a converged window's workgroups return at once: the one block that
+        // may be queued in vain costs a few empty launches).
+        if (!c->h_active) PG_HIP(c, hipHostMalloc((void**)&c->h_active, 2 * sizeof(int32_t), hipHostMallocDefault));
+        c->h_active[0] = c->h_active[1] = c->n_windows;
+        const int n_blocks = (max_iters + 7) / 8;
+        for (int b = 0; b < n_blocks; ++b) {
+            if (b >= 2) {                                       // the answer of block b - 2
+                PG_HIP(c, hipEventSynchronize(c->ev_block[b & 1]));
+                if (c->h_active[b & 1] <= 0) break;
             }
+            for (int it = 8 * b; it < std::min(max_iters, 8 * b + 8); ++it) {
+                hipLaunchKernelGGL(pg::k_em_step, dim3(c->n_windows, c->max_win_inds), dim3(step_threads), lds_step, c->stream, c->d_wins.p, c->d_ioff.p, c->d_full.p, S, n_max);
+                hipLaunchKernelGGL(pg::k_em_update, dim3(c->n_windows), dim3(256), 0, c->stream, c->d_wins.p, c->d_ioff.p, S, max_iters);
+            }
+            PG_HIP(c, hipMemcpyAsync(&c->h_active[b & 1], S.active, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+            PG_HIP(c, hipEventRecord(c->ev_block[b & 1], c->stream));
         }
+        (void)active;
         hipLaunchKernelGGL(pg::k_em_calls, grid2, dim3(256), lds2, c->stream, c->d_wins.p, c->d_ioff.p, c->d_full.p, S, n_max,
                            c->d_best_gen.p, c->d_best_val.p);
     }
