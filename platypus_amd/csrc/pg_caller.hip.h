@@ -684,13 +684,26 @@ __global__ __launch_bounds__(256) void k_em_update(const WinDesc* __restrict__ w
                                                    EmState S, int max_iters)
 {
     __shared__ double s_red[4];
+    __shared__ int s_count[4];
+    extern __shared__ unsigned char s_has[];             // per individual: it has reads
     const int w = blockIdx.x;
     if (S.done[w]) return;
     const WinDesc W = wins[w];
     const int tid = threadIdx.x, n = W.n_hap;
     const int32_t* io = ioff + W.ioff_base;
-    int n_with_data = 0;
-    for (int i = 0; i < W.n_ind; ++i) n_with_data += io[i + 1] != io[i];
+    // which individuals have reads: read once by the whole workgroup (every thread reading all of them
+    // was most of this kernel's time)
+    int mine = 0;
+    for (int i = tid; i < W.n_ind; i += 256) {
+        const int h = io[i + 1] != io[i];
+        s_has[i] = (unsigned char)h;
+        mine += h;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+    if ((tid & 63) == 0) s_count[tid >> 6] = mine;
+    __syncthreads();
+    const int n_with_data = s_count[0] + s_count[1] + s_count[2] + s_count[3];
     const double* sh = S.share + S.share_base[w];
     double ch = 0.0;
     for (int k = tid; k < n; k += 256) {
@@ -704,7 +717,7 @@ __global__ __launch_bounds__(256) void k_em_update(const WinDesc* __restrict__ w
             for (int j = 0; j < 8; ++j) v[j] = i0 + j < W.n_ind ? sh[(int64_t)(i0 + j) * n + k] : 0.0;
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                if (i0 + j < W.n_ind && io[i0 + j + 1] != io[i0 + j]) t += v[j];   // cpopulation.pyx:869-880, individual order
+                if (i0 + j < W.n_ind && s_has[i0 + j]) t += v[j];             // cpopulation.pyx:869-880, individual order
         }
         const double old = S.f[W.hap_base + k], nf = t / (2 * n_with_data);  // :883
         S.f_prev[W.hap_base + k] = old;

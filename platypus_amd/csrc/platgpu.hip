@@ -851,7 +851,7 @@ int pg_caller_launch(pg_ctx* c, int max_iters) {
             }
             for (int it = 8 * b; it < std::min(max_iters, 8 * b + 8); ++it) {
                 hipLaunchKernelGGL(pg::k_em_step, dim3(c->n_windows, c->max_win_inds), dim3(step_threads), lds_step, c->stream, c->d_wins.p, c->d_ioff.p, c->d_full.p, S, n_max);
-                hipLaunchKernelGGL(pg::k_em_update, dim3(c->n_windows), dim3(256), 0, c->stream, c->d_wins.p, c->d_ioff.p, S, max_iters);
+                hipLaunchKernelGGL(pg::k_em_update, dim3(c->n_windows), dim3(256), (size_t)((c->max_win_inds + 15) & ~15), c->stream, c->d_wins.p, c->d_ioff.p, S, max_iters);
             }
             PG_HIP(c, hipMemcpyAsync(&c->h_active[b & 1], S.active, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
             PG_HIP(c, hipEventRecord(c->ev_block[b & 1], c->stream));
