@@ -508,16 +508,16 @@ __global__ __launch_bounds__(1024) void k_em(const WinDesc* __restrict__ wins,
 }
 
 // ---------------------------------------------------------------------------
-// The same EM for batches of few, large windows (many haplotypes x many
-// individuals), where one workgroup per window would leave most of the chip
-// idle: every iteration is a pair of launches.
-//   k_em_step    grid (window, group of four individuals): one wavefront per
-//                individual computes y = P_i f and stores the individual's share
+// The same EM for windows whose matrices do not fit the LDS staging area of k_em
+// (one workgroup per window would wait on global-memory latency, and leave most
+// of the chip idle when the windows are few): every iteration is a pair of launches.
+//   k_em_step    grid (window, individual): the workgroup's wavefronts split the
+//                rows of y = P_i f and store the individual's share
 //                2 f_k y_k / csrSum_i of every haplotype's total
 //   k_em_update  grid (window): adds the shares in individual order, new
 //                frequencies, largest change, convergence flag
-//   k_em_calls   grid (window, group): genotype calls from the last iteration's
-//                old frequencies
+//   k_em_calls   grid (window, individual): genotype calls from the last
+//                iteration's old frequencies
 // Frequencies live in global memory between launches; a window that has
 // converged (or reached max_iters) makes its workgroups return at once, and
 // `active` counts the windows still running so that the host can stop launching.
@@ -549,77 +549,9 @@ __global__ __launch_bounds__(256) void k_em_init(const WinDesc* __restrict__ win
     }
 }
 
-template <int MODE>   // 0: one EM step, 1: genotype calls
-__device__ __forceinline__ void em_individual(const WinDesc* __restrict__ wins, const int32_t* __restrict__ ioff,
-                                              const double* __restrict__ full, EmState S, int n_max,
-                                              int32_t* __restrict__ best_gen, double* __restrict__ best_val)
-{
-    extern __shared__ double em_lds[];
-    const int w = blockIdx.x;
-    if (MODE == 0 && S.done[w]) return;
-    const WinDesc W = wins[w];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = W.n_hap;
-    const int i = blockIdx.y * 4 + wave;
-    double* f = em_lds;
-    double* yv = em_lds + n_max + (size_t)wave * n_max;
-    const double* f_glob = (MODE == 0 ? S.f : S.f_prev) + W.hap_base;
-    for (int k = tid; k < n; k += 256) f[k] = f_glob[k];
-    __syncthreads();
-    if (i >= W.n_ind) return;
-    const int32_t* io = ioff + W.ioff_base;
-    const bool has_reads = io[i + 1] != io[i];
-    if (MODE == 1) {
-        if (!has_reads) {                                                    // cpopulation.pyx:777-780
-            if (lane == 0) { best_gen[W.ind_base + i] = -1; best_val[W.ind_base + i] = 0.0; }
-            return;
-        }
-        if (S.iters[w] == 0) {
-            if (lane == 0) { best_gen[W.ind_base + i] = 0; best_val[W.ind_base + i] = 0.0; }
-            return;
-        }
-    } else if (!has_reads) return;                                           // cpopulation.pyx:834-835
-    const double* P = full + W.full_base + (int64_t)i * n * n;
-    double part = 0.0;
-    for (int k0 = 0; k0 < n; k0 += 256) {
-        const int nc = (n - k0 + 63) >> 6;
-        if (nc >= 4)      part += matvec_pass<4>(P, f, yv, n, k0, lane);
-        else if (nc == 3) part += matvec_pass<3>(P, f, yv, n, k0, lane);
-        else if (nc == 2) part += matvec_pass<2>(P, f, yv, n, k0, lane);
-        else              part += matvec_pass<1>(P, f, yv, n, k0, lane);
-    }
-    const double s = wave_sum(part);
-    if (MODE == 0) {
-        double* sh = S.share + S.share_base[w] + (int64_t)i * n;
-        for (int k = lane; k < n; k += 64) {
-            const double t = 2.0 * f[k] * yv[k];
-            sh[k] = s > 0.0 ? t / s : t;                                     // cpopulation.pyx:852-854
-        }
-        return;
-    }
-    double bv = 0.0;
-    int bj = 0x7fffffff;
-    for (int a = 0; a < n; ++a) {
-        const int64_t row = tri_row_start(a, n);
-        for (int b = a + lane; b < n; b += 64) {
-            double v = P[(int64_t)a * n + b] * f[a] * f[b] * (1 + (a != b));   // cpopulation.pyx:847
-            if (s > 0.0) v /= s;
-            const int j = (int)(row + b - a);
-            if (bj == 0x7fffffff || v > bv) { bv = v; bj = j; }             // cpopulation.pyx:791
-        }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const double ov = __shfl_xor(bv, off);
-        const int oj = __shfl_xor(bj, off);
-        if (oj != 0x7fffffff && (bj == 0x7fffffff || ov > bv || (ov == bv && oj < bj))) { bv = ov; bj = oj; }
-    }
-    if (lane == 0) { best_gen[W.ind_base + i] = bj; best_val[W.ind_base + i] = bv; }
-}
-
 // One EM step for ONE individual per workgroup (grid: window x individual): the wavefronts
 // (four or eight) take an equal share of the matrix rows each and all columns, their partial products are added in
-// wavefront order.  Several times the wavefronts of em_individual<0>, i.e. several times the bytes in
+// wavefront order.  Several times the wavefronts of one wavefront per individual, i.e. several times the bytes in
 // flight: the last iterations of a batch, when few windows are still running, are bound by the
 // memory latency of the few wavefronts left, not by bandwidth.
 __global__ __launch_bounds__(512) void k_em_step(const WinDesc* __restrict__ wins, const int32_t* __restrict__ ioff,
@@ -673,11 +605,86 @@ __global__ __launch_bounds__(512) void k_em_step(const WinDesc* __restrict__ win
     }
 }
 
-__global__ __launch_bounds__(256) void k_em_calls(const WinDesc* __restrict__ wins, const int32_t* __restrict__ ioff,
+// Genotype calls (cpopulation.pyx:773-797) from the last iteration's old frequencies, in the shape of
+// k_em_step: one workgroup per (window, individual), matrix rows split between its wavefronts, for the
+// product that gives csrSum and again for the scan of the upper triangle; the wavefronts' best
+// genotypes are compared in wavefront order, i.e. in genotype order (first maximum wins).
+__global__ __launch_bounds__(512) void k_em_calls(const WinDesc* __restrict__ wins, const int32_t* __restrict__ ioff,
                                                   const double* __restrict__ full, EmState S, int n_max,
                                                   int32_t* __restrict__ best_gen, double* __restrict__ best_val)
 {
-    em_individual<1>(wins, ioff, full, S, n_max, best_gen, best_val);
+    extern __shared__ double em_lds[];
+    __shared__ double s_part[8];
+    __shared__ double s_bv[8];
+    __shared__ int s_bj[8];
+    const int w = blockIdx.x;
+    const WinDesc W = wins[w];
+    const int i = blockIdx.y;
+    if (i >= W.n_ind) return;
+    const int32_t* io = ioff + W.ioff_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_thr = blockDim.x, n_wav = n_thr >> 6;
+    if (io[i + 1] == io[i]) {                                                // cpopulation.pyx:777-780
+        if (tid == 0) { best_gen[W.ind_base + i] = -1; best_val[W.ind_base + i] = 0.0; }
+        return;
+    }
+    if (S.iters[w] == 0) {                                                   // csr still all zero (calloc, :701)
+        if (tid == 0) { best_gen[W.ind_base + i] = 0; best_val[W.ind_base + i] = 0.0; }
+        return;
+    }
+    const int n = W.n_hap;
+    double* f = em_lds;
+    double* yv = em_lds + n_max + (size_t)wave * n_max;
+    const double* f_glob = S.f_prev + W.hap_base;
+    for (int k = tid; k < n; k += n_thr) f[k] = f_glob[k];
+    __syncthreads();
+    const double* P = full + W.full_base + (int64_t)i * n * n;
+    const int rows = (n + n_wav - 1) / n_wav;
+    const int r0 = wave * rows < n ? wave * rows : n, r1 = r0 + rows < n ? r0 + rows : n;
+    for (int k0 = 0; k0 < n; k0 += 256) {
+        const int nc = (n - k0 + 63) >> 6;
+        if (nc >= 4)      matvec_pass<4>(P, f, yv, n, k0, lane, r0, r1);
+        else if (nc == 3) matvec_pass<3>(P, f, yv, n, k0, lane, r0, r1);
+        else if (nc == 2) matvec_pass<2>(P, f, yv, n, k0, lane, r0, r1);
+        else              matvec_pass<1>(P, f, yv, n, k0, lane, r0, r1);
+    }
+    __syncthreads();
+    double part = 0.0;
+    double* y0 = em_lds + n_max;
+    for (int k = tid; k < n; k += n_thr) {
+        double y = y0[k];
+        for (int v = 1; v < n_wav; ++v) y += y0[(size_t)v * n_max + k];      // wavefront order, as in k_em_step
+        part += f[k] * y;
+    }
+    part = wave_sum(part);
+    if (lane == 0) s_part[wave] = part;
+    __syncthreads();
+    double s = s_part[0];                                                    // csrSum of the last iteration
+    for (int v = 1; v < n_wav; ++v) s += s_part[v];
+    double bv = 0.0;
+    int bj = 0x7fffffff;
+    for (int a = r0; a < r1; ++a) {
+        const int64_t row = tri_row_start(a, n);
+        for (int b = a + lane; b < n; b += 64) {
+            double v = P[(int64_t)a * n + b] * f[a] * f[b] * (1 + (a != b));   // cpopulation.pyx:847
+            if (s > 0.0) v /= s;
+            const int j = (int)(row + b - a);
+            if (bj == 0x7fffffff || v > bv) { bv = v; bj = j; }             // cpopulation.pyx:791
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_xor(bv, off);
+        const int oj = __shfl_xor(bj, off);
+        if (oj != 0x7fffffff && (bj == 0x7fffffff || ov > bv || (ov == bv && oj < bj))) { bv = ov; bj = oj; }
+    }
+    if (lane == 0) { s_bv[wave] = bv; s_bj[wave] = bj; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int v = 1; v < n_wav; ++v)
+            if (s_bj[v] != 0x7fffffff && (bj == 0x7fffffff || s_bv[v] > bv)) { bv = s_bv[v]; bj = s_bj[v]; }
+        best_gen[W.ind_base + i] = bj; best_val[W.ind_base + i] = bv;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_em_update(const WinDesc* __restrict__ wins, const int32_t* __restrict__ ioff,

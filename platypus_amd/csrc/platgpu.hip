@@ -827,9 +827,6 @@ int pg_caller_launch(pg_ctx* c, int max_iters) {
         S.f = c->d_freq.p; S.f_prev = c->d_fprev.p; S.share = c->d_share.p; S.iters = c->d_em_iters.p;
         S.change = c->d_em_change.p; S.done = c->d_em_done.p; S.active = c->d_em_done.p + c->n_windows;
         S.share_base = c->d_share_base.p;
-        const dim3 grid2(c->n_windows, (c->max_win_inds + 3) / 4);         // genotype calls: four individuals per workgroup
-        const size_t lds2 = (size_t)5 * n_max * sizeof(double);
-        PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_em_calls), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
         hipLaunchKernelGGL(pg::k_em_init, dim3(c->n_windows), dim3(256), 0, c->stream, c->d_wins.p, c->n_windows, S);
         int32_t active = c->n_windows;
         // wavefronts per individual (the rows of its matrix are split between them): enough to keep loads in
@@ -857,8 +854,9 @@ int pg_caller_launch(pg_ctx* c, int max_iters) {
             PG_HIP(c, hipEventRecord(c->ev_block[b & 1], c->stream));
         }
         (void)active;
-        hipLaunchKernelGGL(pg::k_em_calls, grid2, dim3(256), lds2, c->stream, c->d_wins.p, c->d_ioff.p, c->d_full.p, S, n_max,
-                           c->d_best_gen.p, c->d_best_val.p);
+        PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_em_calls), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step));
+        hipLaunchKernelGGL(pg::k_em_calls, dim3(c->n_windows, c->max_win_inds), dim3(step_threads), lds_step, c->stream,
+                           c->d_wins.p, c->d_ioff.p, c->d_full.p, S, n_max, c->d_best_gen.p, c->d_best_val.p);
     }
     PG_HIP(c, hipGetLastError());
     PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_CALLER_EM + 1], c->stream));
