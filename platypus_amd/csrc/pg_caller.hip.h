@@ -255,49 +255,48 @@ __global__ __launch_bounds__(256) void k_norm(const WinDesc* __restrict__ wins, 
 }
 
 // ---------------------------------------------------------------------------
-// k_norm_tile: the same for windows with many haplotypes.  A wavefront takes an
-// 8 x 8 tile (a, b) of the upper triangle of one individual's matrix: rows of
-// eight cells are read and written as whole 64-byte segments, and the mirrored
-// elements are written after an exchange between lanes (lane (da, db) hands its
-// value to lane (db, da)), so that they too leave as 64-byte segments; k_norm
-// writes the mirror one element per cache line.
-// Grid: (individuals of all windows, tile rows of the largest window), 256 threads: the four
-// wavefronts of a workgroup share the tiles of one row.
+// k_norm_tile: the same for windows with many haplotypes.  A workgroup takes a
+// 32 x 32 tile (a, b) of the upper triangle of one individual's matrix: rows of
+// 32 cells are read and written as 256-byte runs, the tile is kept in LDS, and
+// the mirrored half is written from its transpose, again as 256-byte runs;
+// k_norm writes the mirror one element per cache line.
+// Grid: (individuals of all windows, tile pairs of the largest window), 256 threads.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_norm_tile(const WinDesc* __restrict__ wins, int n_win,
                                                    const unsigned long long* __restrict__ win_max,
                                                    double* __restrict__ cells, double* __restrict__ full)
 {
+    __shared__ double tile[32][33];
     int lo = 0, hi = n_win - 1;                      // last window with ind_base <= blockIdx.x
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
         if (wins[mid].ind_base <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
     }
     const WinDesc W = wins[lo];
-    const int n = W.n_hap, T = (n + 7) >> 3;
-    const int lane = threadIdx.x & 63;
-    const int ta = (int)blockIdx.y;                  // a row of tiles per workgroup, its tiles dealt to the wavefronts
-    if (ta >= T) return;
+    const int n = W.n_hap, T = (n + 31) >> 5;
+    const int tp = (int)blockIdx.y;
+    if (tp >= T * (T + 1) / 2) return;
+    const int ta = tri_row_of(tp, T), tb = ta + (int)(tp - tri_row_start(ta, T));
     const int i = (int)(blockIdx.x - W.ind_base);
-    const int da = lane >> 3, db = lane & 7;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const double mx = from_ordered_bits(win_max[lo]);
     double* F = full + W.full_base + (int64_t)i * n * n;
     double* C = cells + W.cell_base + (int64_t)i * W.n_gen;
-    for (int tb = ta + (int)(threadIdx.x >> 6); tb < T; tb += 4) {
-        const int a = ta * 8 + da, b = tb * 8 + db;
-        const bool valid = a < n && b < n && a <= b;
+    for (int r = ty; r < 32; r += 8) {
+        const int a = ta * 32 + r, b = tb * 32 + tx;
         double p = 0.0;
-        if (valid) {
+        if (a < n && b < n && a <= b) {
             const int64_t c = tri_row_start(a, n) + (b - a);
             p = exp(C[c] - mx);                                              // cpopulation.pyx:732-734
             C[c] = p;
             F[(int64_t)a * n + b] = p;
         }
-        // mirror: this lane now holds element (a', b') = (ta*8 + db, tb*8 + da) and writes F[b'][a']
-        const int src = db * 8 + da;
-        const double q = __hiloint2double(__shfl(__double2hiint(p), src), __shfl(__double2loint(p), src));
-        const int a2 = ta * 8 + db, b2 = tb * 8 + da;
-        if (a2 < n && b2 < n && a2 < b2) F[(int64_t)b2 * n + a2] = q;
+        tile[r][tx] = p;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {               // row b2 of the mirror: elements (a2, b2) of the tile's column r
+        const int b2 = tb * 32 + r, a2 = ta * 32 + tx;
+        if (a2 < n && b2 < n && a2 < b2) F[(int64_t)b2 * n + a2] = tile[tx][r];
     }
 }
 

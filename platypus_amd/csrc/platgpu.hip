@@ -774,8 +774,8 @@ int pg_caller_launch(pg_ctx* c, int max_iters) {
     }
     PG_HIP(c, hipGetLastError());
     if (tile) {
-        const int T = (c->max_win_haps + 7) / 8;
-        hipLaunchKernelGGL(pg::k_norm_tile, dim3((unsigned)c->win_inds_total, (unsigned)T), dim3(256), 0,
+        const int T = (c->max_win_haps + 31) / 32;
+        hipLaunchKernelGGL(pg::k_norm_tile, dim3((unsigned)c->win_inds_total, (unsigned)(T * (T + 1) / 2)), dim3(256), 0,
                            c->stream, c->d_wins.p, c->n_windows, c->d_win_max.p, c->d_cells.p, c->d_full.p);
     } else {
         hipLaunchKernelGGL(pg::k_norm, dim3((unsigned)((c->win_cells + 255) / 256)), dim3(256), 0, c->stream,
