@@ -21,7 +21,8 @@ INFO = [("FR", ".", "Float", "Estimated population frequency"),
         ("MMLQ", ".", "Float", "Median minimum base quality for bases around variant")]
 FILTER = [("ab", "Variant fails allele-bias filter"), ("sb", "Variant fails strand-bias filter"),
           ("badReads", "Variant supported only by reads with low quality bases close to variant position, and not present "
-                       "on both strands.")]
+                       "on both strands."),
+          ("hp10", "Flanking sequence contains homopolymer of length 10 or greater")]   # declared, never raised (cpopulation.pyx:70)
 FORMAT = [("GT", "1", "String", "Unphased genotypes"),
           ("GL", ".", "Float", "Genotype log-likelihoods (log10) for AA,AB and BB genotypes, where A = ref and B = variant. "
                                "Only applicable for bi-allelic sites"),
