@@ -67,7 +67,8 @@ def run_case(n_windows, H, R, n_ind, seed, indel_frac=0.3, empty=None, read_len=
         # of a double (denormal factors carry few digits): their leading digits depend on the order of
         # additions for the reference as for any restatement; no output can show them (FR is printed "%1.4f")
         np.testing.assert_allclose(g_freq, ref["freq"], rtol=RTOL, atol=1e-150)
-        np.testing.assert_allclose(res["max_change"][w], ref["max_change"], rtol=1e-6, atol=1e-15)
+        # the largest change is a difference of two frequencies of order one: its absolute error is a few 1e-16
+        np.testing.assert_allclose(res["max_change"][w], ref["max_change"], rtol=1e-6, atol=1e-14)
         g_best = res["best_gen"][res["ind_off"][w]:res["ind_off"][w + 1]]
         g_val = res["best_val"][res["ind_off"][w]:res["ind_off"][w + 1]]
         np.testing.assert_allclose(g_val, ref["best_val"], rtol=RTOL, atol=1e-300)
