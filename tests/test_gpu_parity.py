@@ -256,3 +256,40 @@ def test_longest_haplotypes_and_mixed_lengths(ctx):
              read_pos=np.array(pos, np.int32), read_mapq=np.full(len(reads), 40, np.int32),
              pair_hap=np.array(ph, np.int32), pair_read=np.array(pr, np.int32))
     _check_batch(ctx, b)
+
+
+def test_long_reads():
+    """reads of 600..4000 bases (a context created for that length): the DP loop, the score range (the
+    reference's int16 costs saturate nowhere but add up over thousands of columns) and the vote counters
+    at lengths far beyond the usual 100-250"""
+    from platypus_amd import native
+    rng = np.random.default_rng(91)
+    A = np.frombuffer(b"ACGT", np.uint8)
+    lens = [9000, 12000, 6000]
+    haps = [A[rng.integers(0, 4, n)] for n in lens]
+    reads, quals, pos, ph, pr = [], [], [], [], []
+    for h, hp in enumerate(haps):
+        for _ in range(40):
+            rl = int(rng.integers(600, 4001))
+            o = int(rng.integers(0, len(hp) - rl - 20))
+            s = hp[o:o + rl].copy()
+            if rng.random() < 0.5:
+                cut = int(rng.integers(100, rl - 100))
+                s = np.concatenate([s[:cut], s[cut + int(rng.integers(1, 6)):]]) if rng.random() < 0.5 else \
+                    np.concatenate([s[:cut], A[rng.integers(0, 4, int(rng.integers(1, 6)))], s[cut:]])
+            sub = rng.random(len(s)) < float(rng.choice([0.0, 0.01, 0.05]))
+            s[sub] = A[rng.integers(0, 4, int(sub.sum()))]
+            reads.append(s); quals.append(rng.integers(2, 42, len(s)).astype(np.uint8)); pos.append(100 + o)
+            ph.append(h); pr.append(len(reads) - 1)
+    b = dict(hap_seq=np.concatenate(haps), hap_off=np.concatenate([[0], np.cumsum(lens)]).astype(np.int64),
+             hap_start=np.full(len(haps), 100, np.int32), hap_varlen=np.array([0, 2, 0], np.int32),
+             read_seq=np.concatenate(reads), read_qual=np.concatenate(quals),
+             read_off=np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.int64),
+             read_pos=np.array(pos, np.int32), read_mapq=np.full(len(reads), 40, np.int32),
+             pair_hap=np.array(ph, np.int32), pair_read=np.array(pr, np.int32))
+    long_ctx = native.AlignContext(0, max_read_len=4096)
+    try:
+        score, anchor, like = _check_batch(long_ctx, b)
+        assert score.max() > 2000                      # far beyond anything a 150-base read can reach
+    finally:
+        long_ctx.close()
