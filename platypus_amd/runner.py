@@ -49,8 +49,9 @@ def sample_names(args):
 
 def call_chunks(chunks, args, tmpdir):
     """Calls every chunk of the list into its own temporary file.  The read buffers of the next
-    stretch are prepared on a helper thread (file reads, BGZF inflation, record decoding, filtering and
-    trimming all run outside the interpreter lock) while the current stretch is being called."""
+    stretches are prepared on helper threads (file reads, BGZF inflation, record decoding, filtering and
+    trimming, the scan for variant candidates: all of it runs outside the interpreter lock) while the current
+    stretch is being called."""
     from concurrent.futures import ThreadPoolExecutor
     from platypus_amd import bamio, pipeline, simulate, vcfout
     from platypus_amd.fastafile import FastaFile
@@ -60,7 +61,7 @@ def call_chunks(chunks, args, tmpdir):
     opts = pipeline.Options(**{k: getattr(args, k) for k in vars(pipeline.Options()) if hasattr(args, k)})
     units = [(ch, s, min(s + args.bufferSize, ch[2])) for ch in chunks for s in range(ch[1], ch[2], args.bufferSize)]
 
-    spent = {"fetch": 0.0, "buffers": 0.0, "wait": 0.0, "call": 0.0, "write": 0.0}
+    spent = {"fetch": 0.0, "buffers": 0.0, "candidates": 0.0, "wait": 0.0, "call": 0.0, "write": 0.0}
 
     local = threading.local()
     opened = []
@@ -83,7 +84,15 @@ def call_chunks(chunks, args, tmpdir):
                                            minGoodQualBases=opts.minGoodQualBases, maxBadQualBases=opts.maxBadQualBases))
             spent["fetch"] += t1 - t0
             spent["buffers"] += time.perf_counter() - t1
-        return bufs
+        if sum(b.readCount for b in bufs) > opts.maxReads:                # variantcaller.pyx:84-88: the stretch is skipped
+            return bufs, None
+        t2 = time.perf_counter()
+        if not hasattr(local, "fa"):                      # a reference file handle per helper thread
+            local.fa = FastaFile(args.refFile, args.refFile + ".fai", parseNCBI=bool(args.parseNCBI))
+        local.fa.setCacheSequence(chrom.encode(), s - 25000, e + 25000)
+        cands = pipeline.candidatesInRegion(chrom.encode(), s, e, bufs, local.fa, opts)
+        spent["candidates"] += time.perf_counter() - t2
+        return bufs, cands
 
     header = "\n".join(vcfout.header(samples, " ".join(sys.argv[1:]))) + "\n"
     for ch in chunks:
@@ -96,7 +105,7 @@ def call_chunks(chunks, args, tmpdir):
         pending = collections.deque(pool.submit(load, u) for u in units[:ahead])
         for i, (ch, s, e) in enumerate(units):
             t0 = time.perf_counter()
-            bufs = pending.popleft().result()
+            bufs, cands = pending.popleft().result()
             spent["wait"] += time.perf_counter() - t0
             if i + ahead < len(units):
                 pending.append(pool.submit(load, units[i + ahead]))
@@ -107,14 +116,14 @@ def call_chunks(chunks, args, tmpdir):
                 out.write(header)
                 current = ch
             chrom = ch[0]
-            if sum(b.readCount for b in bufs) > opts.maxReads:            # variantcaller.pyx:84-88
+            if cands is None:                                 # more reads than maxReads
                 continue
             if args.printVarsAndExit:                         # variantcaller.pyx:110-113
-                for v in pipeline.candidatesInRegion(chrom.encode(), s, e, bufs, fa, opts):
+                for v in cands:
                     print(v)
                 continue
             t0 = time.perf_counter()
-            calls = pipeline.callRegion(chrom.encode(), s, e, bufs, fa, opts)
+            calls = pipeline.callRegion(chrom.encode(), s, e, bufs, fa, opts, variants=cands)
             t1 = time.perf_counter()
             for c in calls:
                 out.write(vcfout.record(c, fa) + "\n")
@@ -126,9 +135,10 @@ def call_chunks(chunks, args, tmpdir):
     for r in readers + opened:
         r.close()
     if os.environ.get("PLATYPUS_AMD_TIMINGS"):             # where a worker's time went (helper thread: fetch, buffers)
-        sys.stderr.write("worker %d: %d calls; helper thread: fetch %.2f s, buffers %.2f s; main thread: waiting %.2f s, "
-                         "calling %.2f s, writing %.2f s\n" % (os.getpid(), n_calls, spent["fetch"], spent["buffers"],
-                                                              spent["wait"], spent["call"], spent["write"]))
+        sys.stderr.write("worker %d: %d calls; helper threads: fetch %.2f s, buffers %.2f s, candidates %.2f s; main thread: "
+                         "waiting %.2f s, calling %.2f s, writing %.2f s\n" % (
+                             os.getpid(), n_calls, spent["fetch"], spent["buffers"], spent["candidates"], spent["wait"],
+                             spent["call"], spent["write"]))
     return n_calls
 
 
@@ -148,7 +158,7 @@ def main(argv=None):
     ap.add_argument("--workersPerGPU", type=int, default=1,
                     help="host processes per device: the host side (BAM decoding, candidates, windows) dominates the "
                          "run time, so several processes can share one GPU")
-    ap.add_argument("--readAhead", type=int, default=4,
+    ap.add_argument("--readAhead", type=int, default=6,
                     help="buffers prepared ahead of the one being called, each on a helper thread of its own")
     ap.add_argument("--nCPU", type=int, default=None,
                     help="the reference's option: taken as the total number of host processes when --workersPerGPU is not given")

@@ -168,10 +168,11 @@ cdef class VariantCandidateGenerator:
         else:
             theVar.addVariant(var)
 
-    cdef getSnpCandidatesFromReadSegment(self, cAlignedRead* read, int readStart, int readOffset, int refOffset,
-                                         int lenSeqToCheck):
-        """variant.pyx:309-365"""
-        cdef int index, readIndex, refIndex, baseQual, alt, k
+    cdef int scanSegment(self, cAlignedRead* read, int readStart, int readOffset, int refOffset,
+                         int lenSeqToCheck) noexcept nogil:
+        """variant.pyx:309-365 for the mismatches A, C, G, T: summed in the table.  Returns 1 if the segment
+        also shows another letter (left to otherLettersInSegment), -1 if memory ran out."""
+        cdef int index, readIndex, refIndex, baseQual, alt, k, rc = 0
         cdef size_t slot
         cdef SnpSums* acc
         cdef SnpSums* grown
@@ -188,10 +189,8 @@ cdef class VariantCandidateGenerator:
             if readChar != refChar and readChar != b'N' and refChar != b'N' and baseQual >= self.minBaseQual:
                 alt = 0 if readChar == b'A' else (1 if readChar == b'C' else (2 if readChar == b'G' else
                                                                                    (3 if readChar == b'T' else -1)))
-                if alt < 0:                                # another letter: the general path
-                    self.addVariantToList(Variant(self.rname, refIndex + self.refSeqStart, bytes([refChar]),
-                                                  bytes([readChar]), 1, 0 if read.isReverse else 1, read.mapq,
-                                                  baseQual, readIndex + 1))
+                if alt < 0:
+                    rc = 1
                     continue
                 # the sums of Variant.__init__ + addVariant (variant.pyx:57-76,107-119), in read order
                 slot = 4 * <size_t>refIndex + alt
@@ -200,7 +199,7 @@ cdef class VariantCandidateGenerator:
                     if self.nSnpSums == self.capSnpSums:
                         grown = <SnpSums*>realloc(self.snpSums, 2 * <size_t>self.capSnpSums * sizeof(SnpSums))
                         if grown == NULL:
-                            raise MemoryError()
+                            return -1
                         self.snpSums = grown
                         self.capSnpSums *= 2
                     k = self.nSnpSums
@@ -216,9 +215,59 @@ cdef class VariantCandidateGenerator:
                 else:
                     acc.fwd += 1
                     acc.fwdW += 1.0 - exp(mLTOT * baseQual)
+        return rc
 
-    cdef getVariantCandidatesFromSingleRead(self, cAlignedRead* read):
-        """variant.pyx:367-474"""
+    cdef otherLettersInSegment(self, cAlignedRead* read, int readStart, int readOffset, int refOffset, int lenSeqToCheck):
+        """the same walk for read letters other than A, C, G, T, N: one Variant object each (rare)"""
+        cdef int index, readIndex, refIndex, baseQual
+        cdef char readChar, refChar
+        for index in range(lenSeqToCheck):
+            readIndex = index + readOffset
+            refIndex = (index + refOffset + readStart) - self.refSeqStart
+            if refIndex < 0 or refIndex >= self.nRef or readIndex >= read.rlen:
+                continue
+            readChar = read.seq[readIndex]
+            refChar = self.refSeq[refIndex]
+            baseQual = read.qual[readIndex]
+            if (readChar != refChar and readChar != b'N' and refChar != b'N' and baseQual >= self.minBaseQual
+                    and readChar != b'A' and readChar != b'C' and readChar != b'G' and readChar != b'T'):
+                self.addVariantToList(Variant(self.rname, refIndex + self.refSeqStart, bytes([refChar]),
+                                              bytes([readChar]), 1, 0 if read.isReverse else 1, read.mapq,
+                                              baseQual, readIndex + 1))
+
+    cdef int scanRead(self, cAlignedRead* read) noexcept nogil:
+        """variant.pyx:367-474, the part that needs no Python object: the matches' mismatches.  Returns 1 if
+        the read has an insertion, a deletion or another letter for candidatesNeedingObjects, -1 if memory ran out."""
+        cdef int readStart = read.pos
+        cdef int flag, length, refOffset = 0, readOffset = 0, cigarIndex, rc = 0, r
+        cdef int cigarLength = read.cigarLen
+        for cigarIndex in range(cigarLength):
+            flag = read.cigarOps[cigarIndex]
+            length = read.cigarLens[cigarIndex]
+            if flag == 1 and self.genIndels:
+                rc = 1
+                readOffset += length
+            elif flag == 2:
+                rc = 1
+                refOffset += length
+            elif flag == 0:
+                if length >= self.minFlank and self.genSNPs:
+                    r = self.scanSegment(read, readStart, readOffset, refOffset, length)
+                    if r < 0:
+                        return -1
+                    if r > 0:
+                        rc = 1
+                readOffset += length
+                refOffset += length
+            elif flag == 3:
+                readOffset += length
+                refOffset += length
+            elif flag == 4:
+                readOffset += length
+        return rc
+
+    cdef candidatesNeedingObjects(self, cAlignedRead* read):
+        """variant.pyx:367-474, the rest: insertions, deletions, letters other than A, C, G, T"""
         cdef int readStart = read.pos, mapQ = read.mapq
         cdef int flag, length, refOffset = 0, readOffset = 0, cigarIndex
         cdef int cigarLength = read.cigarLen
@@ -246,7 +295,7 @@ cdef class VariantCandidateGenerator:
                 refOffset += length
             elif flag == 0:                                                # match
                 if length >= self.minFlank and self.genSNPs:
-                    self.getSnpCandidatesFromReadSegment(read, readStart, readOffset, refOffset, length)
+                    self.otherLettersInSegment(read, readStart, readOffset, refOffset, length)
                 readOffset += length
                 refOffset += length
             elif flag == 3:                                                # skipped reference (as the reference: both advance)
@@ -258,10 +307,27 @@ cdef class VariantCandidateGenerator:
             # genIndels == 0 falls through here as well and leaves readOffset alone, as it does there
 
     def addCandidatesFromBuffer(self, bamReadBuffer buf):
-        """variant.pyx:600-612 over the whole buffer"""
-        cdef int i
-        for i in range(buf.nReads):
-            self.getVariantCandidatesFromSingleRead(buf.cReads[i])
+        """variant.pyx:600-612 over the whole buffer: one pass without the interpreter lock for the mismatches
+        (a helper thread can do it while another buffer is being called), then the reads that need objects"""
+        cdef int i, r, bad = 0
+        cdef int n = buf.nReads
+        cdef unsigned char* todo = <unsigned char*>calloc(n + 1, 1)
+        if todo == NULL:
+            raise MemoryError()
+        with nogil:
+            for i in range(n):
+                r = self.scanRead(buf.cReads[i])
+                if r < 0:
+                    bad = 1
+                    break
+                todo[i] = <unsigned char>r
+        if bad:
+            free(todo)
+            raise MemoryError()
+        for i in range(n):
+            if todo[i]:
+                self.candidatesNeedingObjects(buf.cReads[i])
+        free(todo)
 
     def getCandidates(self, int minSnpSupport=0):
         """all candidates, sorted.  minSnpSupport > 0 leaves out single-base mismatches seen in fewer reads:

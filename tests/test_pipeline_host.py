@@ -260,3 +260,21 @@ def test_region_without_reads_gives_no_calls():
     buf = simulate.buffer_of(reads, 0, 5000)
     assert buf.readCount == 0
     assert pipeline.callRegion(b"sim", 0, 5000, [buf], fa, pipeline.Options(rlen=100)) == []
+
+
+def test_other_letters_still_become_candidates():
+    """a read letter that is neither A, C, G, T nor N goes through the object path (variant.pyx:309-365 makes no
+    difference between letters); the table path beside it is unaffected"""
+    ref = b"ACGTTGCAAGGCTTAACCGGATATCGCGATTACAGGCTAGCTAGGATCCAGTCATGCAAGTCC" * 8
+    fa = FastaFile(sequences={b"c": ref})
+    recs = []
+    for pos, flag in ((200, 0), (203, 0x10)):
+        s = bytearray(ref[pos:pos + 40])
+        s[215 - pos] = ord("R")
+        s[220 - pos] = ord("A") if ref[220:221] != b"A" else ord("C")
+        recs.append((pos, bytes(s), [30] * 40, flag, [(0, 40)], 0, -1, 60))
+    buf = simulate.buffer_of(_records(recs), 0, 504)
+    gen = VariantCandidateGenerator((b"c", 100, 400), fa)
+    gen.addCandidatesFromBuffer(buf)
+    got = {(v.refPos, v.added): (v.nSupportingReads, v.nFwdReads) for v in gen.getCandidates()}
+    assert got[(215, b"R")] == (2, 1) and got[(220, b"A" if ref[220:221] != b"A" else b"C")] == (2, 1) and len(got) == 2
