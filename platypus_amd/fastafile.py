@@ -52,6 +52,9 @@ class FastaFile(object):
             return b"-"
         if self._mem is not None:
             return self._mem[seqName][pos:pos + 1]
+        c = self._cache
+        if c is not None and c[0] == seqName and c[1] <= pos < c[2]:
+            return c[3][pos - c[1]:pos - c[1] + 1]
         self._file.seek(self._offset(t, pos))
         return self._file.read(1).upper()
 
