@@ -793,8 +793,7 @@ int pg_caller_launch(pg_ctx* c, int max_iters) {
     // iteration reads them again, and a window's wavefronts wait on each other's memory latency
     int stage = 0;
     {
-        // (with thousands of windows in the batch, most of them small, occupancy matters more: 32 KiB then)
-        int64_t stage_max = c->n_windows > 2048 ? 4096 : 16384;
+        int64_t stage_max = 16384;
         if (const char* k = std::getenv("PG_EM_STAGE_MAX")) stage_max = std::atoll(k);      // experiments
         const int64_t room = ((int64_t)152 * 1024 - (int64_t)lds) / (int64_t)sizeof(double);   // static LDS and rounding need the rest
         const int64_t cap = std::min(stage_max, room);
