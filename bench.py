@@ -127,6 +127,8 @@ def main():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-e2e", action="store_true", help="skip the file-to-file end-to-end leg")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="kernel-choice override passed to pg_set_option (measurement sweeps)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="wgs",
                     help="pair stream to synthesise; wgs is the configuration the metric is quoted on")
     args = ap.parse_args()
@@ -167,6 +169,8 @@ def main():
                              read_len=L, hap_len=750, seed=synth.SEED + rank, **extra)
     n_pairs = len(batch["pair_hap"])
     ctx = native.AlignContext(device)
+    for opt in args.option:
+        ctx.set_option(*opt.split("=", 1))
     ctx.upload_batch(batch)                                    # inputs resident in HBM from here on
 
     def barrier():

@@ -70,6 +70,20 @@ const char *pg_last_error_string(const pg_ctx *ctx);
 int pg_set_params(pg_ctx *ctx, int gapextend, int nucprior, const char *table, int table_len);
 
 /*
+ * Kernel-choice overrides for tests and measurements; the library's own choice
+ * is always correct, an override only forces one of several equivalent paths.
+ * No counterpart in the reference.  Options (value "default" or "" restores the
+ * library's choice):
+ *   "em_kernel"      small | big | multi   EM path of pg_caller_launch
+ *   "gl_kernel"      cell | tile           genotype-likelihood kernel of pg_caller_launch
+ *   "em_stage_max"   doubles of one window the "big" EM kernel may keep in LDS
+ *   "vote_waves"     1..4 wavefronts per workgroup of the anchoring kernel
+ *   "align_lds_pad"  bytes of unused LDS per workgroup of the DP kernel (lowers occupancy)
+ * The process environment is never consulted.
+ */
+int pg_set_option(pg_ctx *ctx, const char *name, const char *value);
+
+/*
  * Haplotypes of a batch: `n` sequences concatenated in `seq`, sequence i is
  * seq[offsets[i] .. offsets[i+1]).  start_pos = Haplotype.startPos,
  * var_seq_len = Haplotype.varSeqLen (platypus/chaplotype.pxd:8-25,

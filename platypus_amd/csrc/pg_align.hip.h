@@ -72,8 +72,9 @@ struct Align2Args {
     const int32_t* read_mapq;
     const int32_t* pair_hap;
     const int32_t* pair_read;
-    const int32_t* order;
-    const WaveDesc* waves;
+    const int32_t* order;      // slot -> pair of a ragged batch, NULL when every read has the same length
+    const WaveDesc* waves;     // wavefront descriptors of a ragged batch, NULL otherwise
+    const int32_t* status;     // status words of the pair list's preparation (pg_prep.hip.h)
     const int32_t* anchor_in;
     const uint8_t* tab;        // table[h] - 33, 256 entries
     const double* exp_score;
@@ -82,9 +83,17 @@ struct Align2Args {
     int32_t* anchor;
     double* like;
     uint8_t* n_flag;           // per wavefront: 1 = left to the 'N'-aware kernel
-    int n_waves;
+    int n_waves;               // uniform batch: wavefronts; ragged batch: an upper bound, the count is in status
+    int uniform_len;           // uniform batch: the read length
+    int n_pairs;
     int ge, np;
 };
+
+// number of wavefronts with work; 0 if the pair list holds an index out of range
+__device__ __forceinline__ int align_wave_count(const Align2Args& A) {
+    if (A.status[0] != 0x7fffffff) return 0;
+    return A.waves ? min(A.n_waves, A.status[1]) : A.n_waves;
+}
 
 // Per-lane state.  Every DP value is kept with an offset of P*d added, where
 // d is the diagonal of the cell (even lane k: d = 2k, odd lane k: d = 2k+1) and
@@ -332,9 +341,13 @@ template <bool HASN>
 __device__ __forceinline__ void align_wave(const Align2Args& A, int wave, const uint8_t* s_tab)
 {
     const int lane = threadIdx.x & 63;
-    const int w_first = __builtin_amdgcn_readfirstlane(A.waves[wave].first);
-    const int w_count = __builtin_amdgcn_readfirstlane(A.waves[wave].count);
-    const int len2 = __builtin_amdgcn_readfirstlane(A.waves[wave].len), len1 = len2 + 15;
+    int w_first = wave * 64, w_count = min(64, A.n_pairs - wave * 64), len2 = A.uniform_len;
+    if (A.waves) {
+        w_first = __builtin_amdgcn_readfirstlane(A.waves[wave].first);
+        w_count = __builtin_amdgcn_readfirstlane(A.waves[wave].count);
+        len2 = __builtin_amdgcn_readfirstlane(A.waves[wave].len);
+    }
+    const int len1 = len2 + 15;
     const bool active = lane < w_count;
     const int slot = w_first + (active ? lane : w_count - 1);
     const int pair = A.order ? A.order[slot] : slot;
@@ -388,7 +401,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     s_tab[threadIdx.x] = A.tab[threadIdx.x];
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256u + threadIdx.x) >> 6));
-    if (wave >= A.n_waves) return;
+    if (wave >= align_wave_count(A)) return;
     align_wave<false>(A, wave, s_tab);
 }
 
@@ -403,7 +416,7 @@ __global__ __launch_bounds__(256) void k_align2n(const Align2Args A)
     // wavefronts are listed; a persistent grid walking the flags ran 20 % slower
     // than letting the dispatcher place one short-lived wavefront per entry.)
     const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256u + threadIdx.x) >> 6));
-    if (wave >= A.n_waves || !A.n_flag[wave]) return;
+    if (wave >= align_wave_count(A) || !A.n_flag[wave]) return;
     align_wave<true>(A, wave, s_tab);
 }
 

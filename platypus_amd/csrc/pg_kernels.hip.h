@@ -79,13 +79,12 @@ __device__ __forceinline__ uint32_t hash7_packed(const uint32_t* __restrict__ ro
     return (uint32_t)(v >> (2 * (i & 15))) & 0x3fffu;
 }
 
-struct VoteHap {      // one indel-bearing haplotype of k_vote4 and its records [q0, q1)
+struct VoteHap {      // one indel-bearing haplotype of k_vote4 (made once per haplotype upload)
     int32_t hap, len;
     int64_t hap2off;  // word offset of the haplotype's packed row
-    int64_t q0, q1;
 };
 
-struct VoteRec {      // one (read, indel haplotype) pair of k_vote4, built on the host
+struct VoteRec {      // one (read, indel haplotype) pair of k_vote4, built by k_prep_scatter
     int32_t pair;     // index into the pair list
     int32_t rlen;     // read length
     int64_t r2off;    // word offset of the read's packed row
@@ -265,9 +264,15 @@ __device__ __forceinline__ int quad_sum(int v) {
 __global__ __launch_bounds__(256) void k_vote4(const uint32_t* __restrict__ hap2,
                                                const uint32_t* __restrict__ read2,
                                                const VoteHap* __restrict__ vh,
+                                               const int32_t* __restrict__ rec_start,
                                                const VoteRec* __restrict__ vh_recs,
+                                               const int32_t* __restrict__ status,
                                                int32_t* __restrict__ anchor, int cnt_stride, int row_words)
 {
+    // records [rec_start[b], rec_start[b + 1]) belong to indel-bearing haplotype b; a haplotype without
+    // pairs in this list has nothing to do, and nothing runs on a list with an index out of range
+    const int64_t q0 = rec_start[blockIdx.x], q_end = rec_start[blockIdx.x + 1];
+    if (q0 == q_end || status[0] != 0x7fffffff) return;
     extern __shared__ uint32_t lds[];
     uint16_t* tab = reinterpret_cast<uint16_t*>(lds);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -276,10 +281,9 @@ __global__ __launch_bounds__(256) void k_vote4(const uint32_t* __restrict__ hap2
     uint16_t* cnt16 = tab + kHashSize + wave * cnt_stride;
     uint32_t* cnt32 = reinterpret_cast<uint32_t*>(cnt16);
     uint32_t* row = lds + (kHashSize + n_wav * cnt_stride) / 2 + wave * row_words;
-    const VoteHap H = vh[blockIdx.x];                 // one 32-byte descriptor: no chain of dependent loads
+    const VoteHap H = vh[blockIdx.x];                 // one 16-byte descriptor: no chain of dependent loads
     const uint32_t* hw = hap2 + H.hap2off;
     const int L = H.len;
-    const int64_t q0 = H.q0, q_end = H.q1;
 
     // the first record of every read slot and this thread's first four 7-mers of the haplotype
     // are fetched before the table is cleared

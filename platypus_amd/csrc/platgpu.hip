@@ -15,6 +15,7 @@
 #include "../../include/platgpu.h"
 #include "pg_kernels.hip.h"
 #include "pg_align.hip.h"
+#include "pg_prep.hip.h"
 #include "pg_caller.hip.h"
 
 namespace {
@@ -52,15 +53,20 @@ struct pg_ctx {
     int gapextend = 3, nucprior = 2;
     std::string table;
     DevBuf<uint8_t> d_tab1;              // table[h] - 33
-    int vote_waves = 0;                  // PG_VOTE_WAVES: wavefronts per workgroup of the vote kernel (experiments; 0 = default)
-    int lds_pad = 0;                     // PG_ALIGN_LDS_PAD: extra LDS per workgroup, to lower occupancy in experiments
+    // kernel-choice overrides of pg_set_option (tests and measurements); 0 / -1 = the library decides
+    int vote_waves = 0;                  // "vote_waves": wavefronts per workgroup of the vote kernel
+    int lds_pad = 0;                     // "align_lds_pad": extra LDS per workgroup of the DP kernel, lowers its occupancy
+    int gl_kernel = -1;                  // "gl_kernel": 0 cell, 1 tile
+    int em_kernel = -1;                  // "em_kernel": 0 small, 1 big, 2 multi
+    int64_t em_stage_max = 16384;        // "em_stage_max": doubles of a window the big EM kernel may keep in LDS
+    int32_t* h_status = nullptr;         // pinned: status words of the last pair-list preparation
     DevBuf<double> d_exp_score, d_exp_mapq;
 
     // haplotypes
     int n_haps = 0;
     int max_hap_len = 0;
-    std::vector<int64_t> h_hap_off;      // host offsets (lengths)
-    std::vector<int32_t> h_hap_varlen;
+    int n_vote_haps = 0;                 // indel-bearing haplotypes of the upload (var_seq_len != 0)
+    DevBuf<int32_t> d_hap_vote_ord;      // per haplotype: its number among those, -1 for the others
     DevBuf<uint8_t> d_hap_raw, d_hap_has_n;
     DevBuf<uint16_t> d_hapx;
     DevBuf<uint32_t> d_hap2;            // 2-bit packed bases
@@ -72,7 +78,7 @@ struct pg_ctx {
     int n_reads = 0;
     int max_rlen = 0;
     bool uniform_rlen = true;
-    std::vector<int64_t> h_read_off, h_read2off, h_hap2off;
+    DevBuf<int32_t> d_read_len;
     DevBuf<uint8_t> d_rseq, d_rqual;
     DevBuf<uint16_t> d_readx;
     DevBuf<int64_t> d_roff, d_read_xoff, d_read2off;
@@ -81,14 +87,15 @@ struct pg_ctx {
 
     // pairs
     int64_t n_pairs = 0;
-    int n_waves = 0;
-    int n_vote_haps = 0;
-    bool have_order = false;
     DevBuf<int32_t> d_pair_hap, d_pair_read, d_order, d_anchor_in;
-    DevBuf<pg::VoteHap> d_vh;
+    DevBuf<int32_t> d_status, d_hap_cnt, d_hap_cur, d_len_work;
+    DevBuf<pg::VoteHap> d_vh;            // one per indel-bearing haplotype, made by pg_haps_upload
     DevBuf<uint8_t> d_n_flag;
     DevBuf<pg::WaveDesc> d_waves;
     DevBuf<pg::VoteRec> d_vh_recs;
+    DevBuf<int32_t> d_blk32;             // block descriptors of pg_pairs_blocks
+    DevBuf<int64_t> d_blk_base;
+    pg::PairWork work;                   // the arrays above, as the kernels take them
 
     // results
     bool launched = false;
@@ -161,6 +168,131 @@ int upload_params(pg_ctx* c) {
     return PG_OK;
 }
 
+
+// ---- pair lists ---------------------------------------------------------------
+// Everything the kernels need beyond the pair indices (vote records grouped by
+// indel-bearing haplotype; for ragged batches the slot order by read length and
+// the wavefront descriptors) is made on the device by the kernels of
+// pg_prep.hip.h, in the arrays of a pg::PairWork.
+
+unsigned prep_grid(int64_t n_pairs) { return (unsigned)std::min<int64_t>((n_pairs + 255) / 256, 8192); }
+
+// wavefronts of the alignment kernel: exact for a uniform batch, an upper bound for a ragged one
+// (every read length present may end with a partly filled wavefront)
+int wave_bound(const pg_ctx* c, int64_t np) {
+    const int64_t full = (np + 63) / 64;
+    return (int)(c->uniform_rlen ? full : full + std::min<int64_t>(np, c->max_rlen));
+}
+
+// Enqueue the preparation of `np` pairs (device arrays pair_hap / pair_read) into W.
+int enqueue_prep(pg_ctx* c, const pg::PairWork& W, const int32_t* pair_hap, const int32_t* pair_read, int64_t np) {
+    pg::PrepArgs A;
+    A.pair_hap = pair_hap; A.pair_read = pair_read; A.n_pairs = np;
+    A.n_haps = c->n_haps; A.n_reads = c->n_reads; A.n_vote_haps = c->n_vote_haps; A.max_len = c->max_rlen;
+    A.ragged = !c->uniform_rlen;
+    A.hap_vote_ord = c->d_hap_vote_ord.p; A.read_len = c->d_read_len.p; A.read2off = c->d_read2off.p;
+    A.W = W;
+    hipLaunchKernelGGL(pg::k_prep_init, dim3(1), dim3(64), 0, c->stream, W.status);
+    PG_HIP(c, hipMemsetAsync(W.hap_cnt, 0, ((size_t)c->n_vote_haps + 1) * sizeof(int32_t), c->stream));
+    if (A.ragged) PG_HIP(c, hipMemsetAsync(W.len_cnt, 0, ((size_t)c->max_rlen + 2) * sizeof(int32_t), c->stream));
+    hipLaunchKernelGGL(pg::k_prep_count, dim3(prep_grid(np)), dim3(256), 0, c->stream, A);
+    hipLaunchKernelGGL(pg::k_prep_scan, dim3(1), dim3(1024), 0, c->stream, A);
+    hipLaunchKernelGGL(pg::k_prep_scatter, dim3(prep_grid(np)), dim3(256), 0, c->stream, A);
+    if (A.ragged) {
+        const int wb = wave_bound(c, np);
+        hipLaunchKernelGGL(pg::k_prep_waves, dim3((wb + 255) / 256), dim3(256), 0, c->stream, A, wb);
+    }
+    PG_HIP(c, hipGetLastError());
+    return PG_OK;
+}
+
+// The pair list (np pairs) is in c->d_pair_hap / d_pair_read, or on its way there on the stream:
+// size the context's work arrays, prepare, wait, and refuse a list with an index out of range.
+int finish_pairs(pg_ctx* c, int64_t np) {
+    const size_t L = (size_t)c->max_rlen + 2;
+    const int wb = wave_bound(c, np);
+    PG_HIP(c, c->d_status.reserve(pg::ST_WORDS));
+    PG_HIP(c, c->d_hap_cnt.reserve((size_t)c->n_vote_haps + 1));
+    PG_HIP(c, c->d_hap_cur.reserve((size_t)c->n_vote_haps + 1));
+    PG_HIP(c, c->d_vh_recs.reserve(np));
+    PG_HIP(c, c->d_anchor_in.reserve(np));
+    PG_HIP(c, c->d_n_flag.reserve((size_t)wb + 64));
+    PG_HIP(c, c->d_score.reserve(np));
+    PG_HIP(c, c->d_anchor.reserve(np));
+    PG_HIP(c, c->d_like.reserve(np));
+    if (!c->uniform_rlen) {
+        PG_HIP(c, c->d_len_work.reserve(4 * L));
+        PG_HIP(c, c->d_order.reserve(np));
+        PG_HIP(c, c->d_waves.reserve((size_t)wb + 1));
+    }
+    pg::PairWork& W = c->work;
+    W.status = c->d_status.p; W.hap_cnt = c->d_hap_cnt.p; W.hap_cur = c->d_hap_cur.p;
+    W.len_cnt = c->d_len_work.p; W.len_slot = c->d_len_work.p + L; W.len_wave = c->d_len_work.p + 2 * L;
+    W.len_cur = c->d_len_work.p + 3 * L;
+    W.order = c->uniform_rlen ? nullptr : c->d_order.p;
+    W.waves = c->uniform_rlen ? nullptr : c->d_waves.p;
+    W.recs = c->d_vh_recs.p; W.anchor_in = c->d_anchor_in.p; W.n_flag = c->d_n_flag.p;
+    int rc = enqueue_prep(c, W, c->d_pair_hap.p, c->d_pair_read.p, np);
+    if (rc != PG_OK) return rc;
+    PG_HIP(c, hipMemcpyAsync(c->h_status, W.status, pg::ST_WORDS * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    PG_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->h_status[pg::ST_BAD_PAIR] != 0x7fffffff)
+        return fail(c, PG_ERR_INVALID, "pair %d refers to a haplotype or read outside the uploaded batches",
+                    c->h_status[pg::ST_BAD_PAIR]);
+    c->n_pairs = np;
+    return PG_OK;
+}
+
+// Enqueue anchoring + alignment of a prepared pair list; results go to score / anchor / like (device).
+int enqueue_align(pg_ctx* c, const pg::PairWork& W, const int32_t* pair_hap, const int32_t* pair_read, int64_t np,
+                  int32_t* score, int32_t* anchor, double* like) {
+    // anchoring of pairs on indel-bearing haplotypes
+    PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_ANCHOR], c->stream));
+    if (c->n_vote_haps > 0) {
+        int cnt_stride = c->max_hap_len + c->max_rlen + 8;
+        cnt_stride += cnt_stride & 1;
+        const int row_words = (c->max_rlen + 15) / 16 + 2;
+        // four lanes per read, four wavefronts per haplotype
+        int n_wav = c->vote_waves > 0 ? std::min(c->vote_waves, 4) : 4;
+        auto lds_bytes = [&](int w) { return (size_t)pg::kHashSize * 2 + (size_t)w * (cnt_stride * 2 + row_words * 4); };
+        while (n_wav > 1 && lds_bytes(n_wav) > 160 * 1024) n_wav >>= 1;
+        const size_t lds = lds_bytes(n_wav);
+        if (lds > 160 * 1024)
+            return fail(c, PG_ERR_UNSUPPORTED, "vote counters for haplotype length %d need %zu bytes of LDS", c->max_hap_len, lds);
+        PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_vote4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(pg::k_vote4, dim3(c->n_vote_haps), dim3(64 * n_wav), lds, c->stream, c->d_hap2.p,
+                           c->d_read2.p, c->d_vh.p, W.hap_cnt, W.recs, W.status, W.anchor_in, cnt_stride, row_words);
+        PG_HIP(c, hipGetLastError());
+    }
+    PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_ANCHOR + 1], c->stream));
+    c->ev_valid[PG_K_ANCHOR] = true;
+
+    const int n_waves = wave_bound(c, np);
+    pg::Align2Args B;
+    B.hapx = c->d_hapx.p; B.hap_xoff = c->d_hap_doff.p; B.hap_len = c->d_hap_len.p;
+    B.hap_start = c->d_hap_start.p; B.hap_varlen = c->d_hap_varlen.p; B.hap_has_n = c->d_hap_has_n.p;
+    B.readx = c->d_readx.p; B.read_xoff = c->d_read_xoff.p;
+    B.read_pos = c->d_read_pos.p; B.read_mapq = c->d_read_mapq.p;
+    B.pair_hap = pair_hap; B.pair_read = pair_read;
+    B.order = W.order; B.waves = W.waves; B.status = W.status;
+    B.anchor_in = W.anchor_in; B.tab = c->d_tab1.p;
+    B.exp_score = c->d_exp_score.p; B.exp_mapq = c->d_exp_mapq.p;
+    B.score = score; B.anchor = anchor; B.like = like;
+    B.n_flag = W.n_flag;
+    B.n_waves = n_waves; B.uniform_len = c->max_rlen; B.n_pairs = (int)np;
+    B.ge = c->gapextend; B.np = c->nucprior;
+    if (c->lds_pad > 0)
+        PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_align2), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_pad));
+    PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_ALIGN], c->stream));
+    hipLaunchKernelGGL(pg::k_align2, dim3((n_waves + 3) / 4), dim3(256), c->lds_pad, c->stream, B);
+    PG_HIP(c, hipGetLastError());
+    hipLaunchKernelGGL(pg::k_align2n, dim3((n_waves + 3) / 4), dim3(256), 0, c->stream, B);
+    PG_HIP(c, hipGetLastError());
+    PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_ALIGN + 1], c->stream));
+    c->ev_valid[PG_K_ALIGN] = true;
+    return PG_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -192,8 +324,6 @@ int pg_ctx_create(int device_ordinal, int max_read_len, pg_ctx** out) {
     c->device = device_ordinal;
     c->max_read_len = max_read_len;
     c->table = kDefaultTable;
-    if (const char* k = std::getenv("PG_VOTE_WAVES")) c->vote_waves = std::max(1, std::min(16, std::atoi(k)));
-    if (const char* k = std::getenv("PG_ALIGN_LDS_PAD")) c->lds_pad = std::atoi(k);
     if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
         delete c;
         return fail(nullptr, PG_ERR_HIP, "cannot create a stream on device %d", device_ordinal);
@@ -202,6 +332,11 @@ int pg_ctx_create(int device_ordinal, int max_read_len, pg_ctx** out) {
         if (hipEventCreate(&e) != hipSuccess) { delete c; return fail(nullptr, PG_ERR_HIP, "hipEventCreate failed"); }
     for (auto& e : c->ev_block)
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete c; return fail(nullptr, PG_ERR_HIP, "hipEventCreate failed"); }
+    if (hipHostMalloc((void**)&c->h_status, pg::ST_WORDS * sizeof(int32_t), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&c->h_active, 2 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) {
+        delete c;
+        return fail(nullptr, PG_ERR_HIP, "cannot allocate pinned status words");
+    }
     int rc = upload_params(c);
     if (rc != PG_OK) { g_create_error = c->err; delete c; return rc; }
     *out = c;
@@ -222,7 +357,9 @@ int pg_ctx_destroy(pg_ctx* c) {
     c->d_rseq.release(); c->d_rqual.release(); c->d_roff.release();
     c->d_read_pos.release(); c->d_read_mapq.release(); c->d_flag.release();
     c->d_pair_hap.release(); c->d_pair_read.release(); c->d_order.release();
-    c->d_vh.release(); c->d_anchor_in.release();
+    c->d_vh.release(); c->d_anchor_in.release(); c->d_hap_vote_ord.release(); c->d_read_len.release();
+    c->d_status.release(); c->d_hap_cnt.release(); c->d_hap_cur.release(); c->d_len_work.release();
+    c->d_blk32.release(); c->d_blk_base.release();
     c->d_n_flag.release(); c->d_wins.release(); c->d_ioff.release(); c->d_em_iters.release(); c->d_best_gen.release();
     c->d_var_win.release(); c->d_cells.release(); c->d_full.release(); c->d_freq.release(); c->d_em_change.release();
     c->d_best_val.release(); c->d_var_prior.release(); c->d_var_out.release(); c->d_var_moff.release(); c->d_win_max.release(); c->d_fprev.release(); c->d_share.release(); c->d_em_done.release(); c->d_share_base.release(); c->d_rows.release(); c->d_cmp_bytes.release(); c->d_cmp_ints.release(); c->d_var_mask.release(); c->d_vh_recs.release(); c->d_waves.release(); c->d_score.release(); c->d_anchor.release(); c->d_like.release();
@@ -230,6 +367,7 @@ int pg_ctx_destroy(pg_ctx* c) {
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_block) if (e) (void)hipEventDestroy(e);
     if (c->h_active) (void)hipHostFree(c->h_active);
+    if (c->h_status) (void)hipHostFree(c->h_status);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return PG_OK;
@@ -252,6 +390,29 @@ int pg_set_params(pg_ctx* c, int gapextend, int nucprior, const char* table, int
     c->n_pairs = 0;
     c->launched = false;
     return upload_params(c);
+}
+
+int pg_set_option(pg_ctx* c, const char* name, const char* value) {
+    if (!c) return PG_ERR_INVALID;
+    if (!name || !value) return fail(c, PG_ERR_INVALID, "pg_set_option: NULL argument");
+    const std::string n = name, v = value;
+    const bool dflt = v.empty() || v == "default";
+    if (n == "em_kernel") {
+        if (dflt) c->em_kernel = -1; else if (v == "small") c->em_kernel = 0; else if (v == "big") c->em_kernel = 1;
+        else if (v == "multi") c->em_kernel = 2; else return fail(c, PG_ERR_INVALID, "em_kernel: small, big, multi or default");
+    } else if (n == "gl_kernel") {
+        if (dflt) c->gl_kernel = -1; else if (v == "cell") c->gl_kernel = 0; else if (v == "tile") c->gl_kernel = 1;
+        else return fail(c, PG_ERR_INVALID, "gl_kernel: cell, tile or default");
+    } else if (n == "em_stage_max") {
+        c->em_stage_max = dflt ? 16384 : std::max<int64_t>(0, std::atoll(value));
+    } else if (n == "vote_waves") {
+        c->vote_waves = dflt ? 0 : std::max(1, std::min(4, std::atoi(value)));
+    } else if (n == "align_lds_pad") {
+        c->lds_pad = dflt ? 0 : std::max(0, std::min(159 * 1024, std::atoi(value)));
+    } else {
+        return fail(c, PG_ERR_INVALID, "pg_set_option: unknown option '%s'", name);
+    }
+    return PG_OK;
 }
 
 int pg_haps_upload(pg_ctx* c, int n, const char* seq, const int64_t* off,
@@ -310,10 +471,20 @@ int pg_haps_upload(pg_ctx* c, int n, const char* seq, const int64_t* off,
     hipLaunchKernelGGL(pg::k_pack_codes, dim3(std::min((n + 3) / 4, 65536)), dim3(256), 0, c->stream, c->d_hap_raw.p,
                        c->d_hap_soff.p, c->d_hap2off.p, c->d_hap2.p, n);
     PG_HIP(c, hipGetLastError());
+    // the indel-bearing haplotypes: one workgroup of the vote kernel each
+    std::vector<int32_t> ord(n);
+    std::vector<pg::VoteHap> vh;
+    for (int i = 0; i < n; ++i) {
+        ord[i] = var_seq_len[i] != 0 ? (int32_t)vh.size() : -1;
+        if (var_seq_len[i] != 0) vh.push_back({i, len[i], off2[i]});
+    }
+    PG_HIP(c, c->d_hap_vote_ord.reserve(n));
+    PG_HIP(c, c->d_vh.reserve(vh.size() + 1));
+    PG_HIP(c, hipMemcpyAsync(c->d_hap_vote_ord.p, ord.data(), n * 4, hipMemcpyHostToDevice, c->stream));
+    if (!vh.empty())
+        PG_HIP(c, hipMemcpyAsync(c->d_vh.p, vh.data(), vh.size() * sizeof(pg::VoteHap), hipMemcpyHostToDevice, c->stream));
     PG_HIP(c, hipStreamSynchronize(c->stream));   // host vectors above go out of scope
-    c->h_hap_off.assign(soff.begin(), soff.end());
-    c->h_hap2off.swap(off2);
-    c->h_hap_varlen.assign(var_seq_len, var_seq_len + n);
+    c->n_vote_haps = (int)vh.size();
     c->max_hap_len = maxlen;
     c->n_haps = n;
     return PG_OK;
@@ -346,7 +517,11 @@ int pg_reads_upload(pg_ctx* c, int n, const char* seq, const char* qual, const i
     PG_HIP(c, c->d_read_pos.reserve(n));
     PG_HIP(c, c->d_read_mapq.reserve(n));
     std::vector<int64_t> roff(n + 1), xoff(n + 1);
+    std::vector<int32_t> rlen(n);
     for (int i = 0; i <= n; ++i) roff[i] = off[i] - off[0];
+    for (int i = 0; i < n; ++i) rlen[i] = (int32_t)(roff[i + 1] - roff[i]);
+    PG_HIP(c, c->d_read_len.reserve(n));
+    PG_HIP(c, hipMemcpyAsync(c->d_read_len.p, rlen.data(), n * 4, hipMemcpyHostToDevice, c->stream));
     xoff[0] = 0;                                   // 8-element aligned rows with >= 24 padding elements
     for (int i = 0; i < n; ++i) xoff[i + 1] = xoff[i] + ((roff[i + 1] - roff[i] + 7) / 8) * 8 + 24;
     PG_HIP(c, c->d_readx.reserve((size_t)xoff[n] + 64));
@@ -373,8 +548,6 @@ int pg_reads_upload(pg_ctx* c, int n, const char* seq, const char* qual, const i
     PG_HIP(c, hipMemcpyAsync(&bad, c->d_flag.p, sizeof bad, hipMemcpyDeviceToHost, c->stream));
     PG_HIP(c, hipStreamSynchronize(c->stream));
     if (bad) return fail(c, PG_ERR_UNSUPPORTED, "a base quality above 127 was found");
-    c->h_read_off.swap(roff);
-    c->h_read2off.swap(off2);
     c->max_rlen = maxl;
     c->uniform_rlen = (maxl == minl);
     c->n_reads = n;
@@ -390,100 +563,19 @@ int pg_pairs_upload(pg_ctx* c, int64_t np, const int32_t* hap_idx, const int32_t
     PG_HIP(c, hipSetDevice(c->device));
     c->n_pairs = 0; c->launched = false;
     if (np == 0) return PG_OK;
-    for (int64_t p = 0; p < np; ++p)
-        if ((uint32_t)hap_idx[p] >= (uint32_t)c->n_haps || (uint32_t)read_idx[p] >= (uint32_t)c->n_reads)
-            return fail(c, PG_ERR_INVALID, "pair %lld refers to haplotype %d / read %d outside the uploaded batches",
-                        (long long)p, hap_idx[p], read_idx[p]);
-
-    // ---- wavefronts of equal read length ------------------------------------
-    std::vector<pg::WaveDesc> waves;
-    std::vector<int32_t> order;
-    c->have_order = !c->uniform_rlen;
-    if (c->uniform_rlen) {
-        const int len = c->max_rlen;
-        waves.reserve((size_t)(np + 63) / 64);
-        for (int64_t s = 0; s < np; s += 64)
-            waves.push_back({(int32_t)s, (int32_t)std::min<int64_t>(64, np - s), len, 0});
-    } else {
-        // counting sort by read length, stable: neighbours stay neighbours
-        std::vector<int64_t> cnt(c->max_rlen + 2, 0);
-        for (int64_t p = 0; p < np; ++p) cnt[(c->h_read_off[read_idx[p] + 1] - c->h_read_off[read_idx[p]]) + 1]++;
-        for (size_t l = 1; l < cnt.size(); ++l) cnt[l] += cnt[l - 1];
-        order.resize(np);
-        std::vector<int64_t> cur(cnt.begin(), cnt.end() - 1);
-        for (int64_t p = 0; p < np; ++p) {
-            const int l = (int)(c->h_read_off[read_idx[p] + 1] - c->h_read_off[read_idx[p]]);
-            order[cur[l]++] = (int32_t)p;
-        }
-        for (int l = 1; l <= c->max_rlen; ++l)
-            for (int64_t s = cnt[l]; s < cnt[l + 1]; s += 64)
-                waves.push_back({(int32_t)s, (int32_t)std::min<int64_t>(64, cnt[l + 1] - s), l, 0});
-    }
-
-    // ---- pairs on indel-bearing haplotypes, grouped by haplotype ---------------
-    std::vector<int32_t> vh_pairs;
-    std::vector<pg::VoteRec> vh_recs;
-    std::vector<pg::VoteHap> vh;
-    {
-        std::vector<int64_t> per_hap(c->n_haps + 1, 0);
-        int64_t nv = 0;
-        for (int64_t p = 0; p < np; ++p)
-            if (c->h_hap_varlen[hap_idx[p]] != 0) { per_hap[hap_idx[p] + 1]++; ++nv; }
-        if (nv > 0) {
-            std::vector<int64_t> start(c->n_haps + 1, 0);
-            for (int h = 0; h < c->n_haps; ++h) start[h + 1] = start[h] + per_hap[h + 1];
-            vh_pairs.resize(nv);
-            std::vector<int64_t> cur(start.begin(), start.end() - 1);
-            for (int64_t p = 0; p < np; ++p)
-                if (c->h_hap_varlen[hap_idx[p]] != 0) vh_pairs[cur[hap_idx[p]]++] = (int32_t)p;
-            vh_recs.resize(nv);
-            for (int64_t i = 0; i < nv; ++i) {
-                const int r = read_idx[vh_pairs[i]];
-                vh_recs[i] = {vh_pairs[i], (int32_t)(c->h_read_off[r + 1] - c->h_read_off[r]), c->h_read2off[r]};
-            }
-            for (int h = 0; h < c->n_haps; ++h)
-                if (start[h + 1] > start[h])
-                    vh.push_back({h, (int32_t)(c->h_hap_off[h + 1] - c->h_hap_off[h]), c->h_hap2off[h], start[h], start[h + 1]});
-        }
-    }
-    c->n_vote_haps = (int)vh.size();
-
     PG_HIP(c, c->d_pair_hap.reserve(np));
     PG_HIP(c, c->d_pair_read.reserve(np));
-    PG_HIP(c, c->d_waves.reserve(waves.size()));
-    PG_HIP(c, c->d_score.reserve(np));
-    PG_HIP(c, c->d_anchor.reserve(np));
-    PG_HIP(c, c->d_anchor_in.reserve(np));
-    PG_HIP(c, c->d_like.reserve(np));
-    PG_HIP(c, c->d_n_flag.reserve(waves.size() + 64));
     PG_HIP(c, hipMemcpyAsync(c->d_pair_hap.p, hap_idx, np * 4, hipMemcpyHostToDevice, c->stream));
     PG_HIP(c, hipMemcpyAsync(c->d_pair_read.p, read_idx, np * 4, hipMemcpyHostToDevice, c->stream));
-    PG_HIP(c, hipMemcpyAsync(c->d_waves.p, waves.data(), waves.size() * sizeof(pg::WaveDesc), hipMemcpyHostToDevice, c->stream));
-    if (c->have_order) {
-        PG_HIP(c, c->d_order.reserve(np));
-        PG_HIP(c, hipMemcpyAsync(c->d_order.p, order.data(), np * 4, hipMemcpyHostToDevice, c->stream));
-    }
-    if (c->n_vote_haps > 0) {
-        PG_HIP(c, c->d_vh.reserve(vh.size()));
-        PG_HIP(c, hipMemcpyAsync(c->d_vh.p, vh.data(), vh.size() * sizeof(pg::VoteHap), hipMemcpyHostToDevice, c->stream));
-        PG_HIP(c, c->d_vh_recs.reserve(vh_recs.size()));
-        PG_HIP(c, hipMemcpyAsync(c->d_vh_recs.p, vh_recs.data(), vh_recs.size() * sizeof(pg::VoteRec), hipMemcpyHostToDevice, c->stream));
-    }
-    PG_HIP(c, hipStreamSynchronize(c->stream));
-    c->n_waves = (int)waves.size();
-    c->n_pairs = np;
-    return PG_OK;
+    return finish_pairs(c, np);
 }
 
 int pg_pairs_block(pg_ctx* c, int hap_lo, int hap_hi, int read_lo, int read_hi) {
     if (!c) return PG_ERR_INVALID;
     if (hap_lo < 0 || hap_hi < hap_lo || hap_hi > c->n_haps || read_lo < 0 || read_hi < read_lo || read_hi > c->n_reads)
         return fail(c, PG_ERR_INVALID, "pg_pairs_block: range outside the uploaded batches");
-    const int64_t nh = hap_hi - hap_lo, nr = read_hi - read_lo;
-    std::vector<int32_t> hi((size_t)(nh * nr)), ri((size_t)(nh * nr));
-    for (int64_t h = 0; h < nh; ++h)
-        for (int64_t r = 0; r < nr; ++r) { hi[h * nr + r] = (int32_t)(hap_lo + h); ri[h * nr + r] = (int32_t)(read_lo + r); }
-    return pg_pairs_upload(c, nh * nr, hi.data(), ri.data());
+    const int32_t nh = hap_hi - hap_lo, nr = read_hi - read_lo;
+    return pg_pairs_blocks(c, 1, &hap_lo, &nh, &read_lo, &nr, nullptr);
 }
 
 int pg_pairs_blocks(pg_ctx* c, int nb, const int32_t* hap_lo, const int32_t* n_haps,
@@ -491,72 +583,46 @@ int pg_pairs_blocks(pg_ctx* c, int nb, const int32_t* hap_lo, const int32_t* n_h
     if (!c) return PG_ERR_INVALID;
     if (nb < 0 || (nb > 0 && (!hap_lo || !n_haps || !read_lo || !n_reads)))
         return fail(c, PG_ERR_INVALID, "pg_pairs_blocks: bad arguments");
+    if (c->n_haps == 0 || c->n_reads == 0)
+        return fail(c, PG_ERR_STATE, "upload haplotypes and reads before pairs");
+    std::vector<int64_t> base((size_t)nb + 1);
     int64_t total = 0;
     for (int b = 0; b < nb; ++b) {
         if (hap_lo[b] < 0 || n_haps[b] < 0 || (int64_t)hap_lo[b] + n_haps[b] > c->n_haps || read_lo[b] < 0 ||
             n_reads[b] < 0 || (int64_t)read_lo[b] + n_reads[b] > c->n_reads)
             return fail(c, PG_ERR_INVALID, "pg_pairs_blocks: block %d reaches outside the uploaded batches", b);
+        base[b] = total;
         if (pair_base) pair_base[b] = total;
         total += (int64_t)n_haps[b] * n_reads[b];
     }
+    base[nb] = total;
     if (total > 0x7fffffffLL) return fail(c, PG_ERR_INVALID, "pg_pairs_blocks: %lld pairs", (long long)total);
-    std::vector<int32_t> hi((size_t)total), ri((size_t)total);
-    int64_t p = 0;
-    for (int b = 0; b < nb; ++b)
-        for (int32_t h = 0; h < n_haps[b]; ++h)
-            for (int32_t r = 0; r < n_reads[b]; ++r, ++p) { hi[p] = hap_lo[b] + h; ri[p] = read_lo[b] + r; }
-    return pg_pairs_upload(c, total, hi.data(), ri.data());
+    PG_HIP(c, hipSetDevice(c->device));
+    c->n_pairs = 0; c->launched = false;
+    if (total == 0) return PG_OK;
+    // the blocks go up as descriptors (12 bytes each + a base); the pair list is written on the device
+    PG_HIP(c, c->d_blk32.reserve((size_t)3 * nb));
+    PG_HIP(c, c->d_blk_base.reserve((size_t)nb + 1));
+    PG_HIP(c, c->d_pair_hap.reserve(total));
+    PG_HIP(c, c->d_pair_read.reserve(total));
+    PG_HIP(c, hipMemcpyAsync(c->d_blk32.p, hap_lo, 4 * (size_t)nb, hipMemcpyHostToDevice, c->stream));
+    PG_HIP(c, hipMemcpyAsync(c->d_blk32.p + nb, read_lo, 4 * (size_t)nb, hipMemcpyHostToDevice, c->stream));
+    PG_HIP(c, hipMemcpyAsync(c->d_blk32.p + 2 * (size_t)nb, n_reads, 4 * (size_t)nb, hipMemcpyHostToDevice, c->stream));
+    PG_HIP(c, hipMemcpyAsync(c->d_blk_base.p, base.data(), 8 * ((size_t)nb + 1), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(pg::k_expand_blocks, dim3(prep_grid(total)), dim3(256), 0, c->stream, nb, c->d_blk32.p,
+                       c->d_blk32.p + nb, c->d_blk32.p + 2 * (size_t)nb, c->d_blk_base.p, c->d_pair_hap.p,
+                       c->d_pair_read.p, total);
+    PG_HIP(c, hipGetLastError());
+    return finish_pairs(c, total);      // synchronises: `base` and the caller's arrays are free after it
 }
 
 int pg_align_launch(pg_ctx* c) {
     if (!c) return PG_ERR_INVALID;
     if (c->n_pairs == 0) return fail(c, PG_ERR_STATE, "no pairs uploaded");
     PG_HIP(c, hipSetDevice(c->device));
-    // anchoring of pairs on indel-bearing haplotypes
-    PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_ANCHOR], c->stream));
-    if (c->n_vote_haps > 0) {
-        int cnt_stride = c->max_hap_len + c->max_rlen + 8;
-        cnt_stride += cnt_stride & 1;
-        // as many reads in flight per haplotype as LDS allows, two workgroups per CU if possible
-        const int row_words = (c->max_rlen + 15) / 16 + 2;
-        // four lanes per read, four wavefronts per haplotype
-        int n_wav = c->vote_waves > 0 ? std::min(c->vote_waves, 4) : 4;
-        auto lds_bytes = [&](int w) { return (size_t)pg::kHashSize * 2 + (size_t)w * (cnt_stride * 2 + row_words * 4); };
-        while (n_wav > 1 && lds_bytes(n_wav) > 160 * 1024) n_wav >>= 1;
-        const size_t lds = lds_bytes(n_wav);
-        if (lds > 160 * 1024)
-            return fail(c, PG_ERR_UNSUPPORTED, "vote counters for haplotype length %d need %zu bytes of LDS", c->max_hap_len, lds);
-        PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_vote4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(pg::k_vote4, dim3(c->n_vote_haps), dim3(64 * n_wav), lds, c->stream, c->d_hap2.p,
-                           c->d_read2.p, c->d_vh.p, c->d_vh_recs.p, c->d_anchor_in.p, cnt_stride, row_words);
-        PG_HIP(c, hipGetLastError());
-    }
-    PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_ANCHOR + 1], c->stream));
-    c->ev_valid[PG_K_ANCHOR] = true;
-
-    pg::Align2Args B;
-    B.hapx = c->d_hapx.p; B.hap_xoff = c->d_hap_doff.p; B.hap_len = c->d_hap_len.p;
-    B.hap_start = c->d_hap_start.p; B.hap_varlen = c->d_hap_varlen.p; B.hap_has_n = c->d_hap_has_n.p;
-    B.readx = c->d_readx.p; B.read_xoff = c->d_read_xoff.p;
-    B.read_pos = c->d_read_pos.p; B.read_mapq = c->d_read_mapq.p;
-    B.pair_hap = c->d_pair_hap.p; B.pair_read = c->d_pair_read.p;
-    B.order = c->have_order ? c->d_order.p : nullptr;
-    B.waves = c->d_waves.p; B.anchor_in = c->d_anchor_in.p; B.tab = c->d_tab1.p;
-    B.exp_score = c->d_exp_score.p; B.exp_mapq = c->d_exp_mapq.p;
-    B.score = c->d_score.p; B.anchor = c->d_anchor.p; B.like = c->d_like.p;
-    B.n_flag = c->d_n_flag.p;
-    B.n_waves = c->n_waves; B.ge = c->gapextend; B.np = c->nucprior;
-    if (c->lds_pad > 0)
-        PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_align2), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_pad));
-    PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_ALIGN], c->stream));
-    {
-        hipLaunchKernelGGL(pg::k_align2, dim3((c->n_waves + 3) / 4), dim3(256), c->lds_pad, c->stream, B);
-        PG_HIP(c, hipGetLastError());
-        hipLaunchKernelGGL(pg::k_align2n, dim3((c->n_waves + 3) / 4), dim3(256), 0, c->stream, B);
-    }
-    PG_HIP(c, hipGetLastError());
-    PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_ALIGN + 1], c->stream));
-    c->ev_valid[PG_K_ALIGN] = true;
+    int rc = enqueue_align(c, c->work, c->d_pair_hap.p, c->d_pair_read.p, c->n_pairs,
+                           c->d_score.p, c->d_anchor.p, c->d_like.p);
+    if (rc != PG_OK) return rc;
     c->launched = true;
     return PG_OK;
 }
@@ -760,8 +826,7 @@ int pg_caller_launch(pg_ctx* c, int max_iters) {
     PG_HIP(c, c->d_win_max.reserve((size_t)c->n_windows));
     hipLaunchKernelGGL(pg::k_fill_u64, dim3((c->n_windows + 255) / 256), dim3(256), 0, c->stream,
                        c->d_win_max.p, c->n_windows, -1e7);
-    const char* glk = std::getenv("PG_GL_KERNEL");           // experiments / tests: "cell" or "tile"
-    const bool tile = glk ? glk[0] == 't' : c->max_win_haps >= 24;   // >= 300 genotypes: a workgroup has work
+    const bool tile = c->gl_kernel >= 0 ? c->gl_kernel == 1 : c->max_win_haps >= 24;   // >= 300 genotypes: a workgroup has work
     if (tile) {
         const int lds_doubles = std::max(6 * 1024, c->max_win_haps);  // 48 KiB, at least one read per chunk
         PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_gl_tile), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -793,8 +858,7 @@ int pg_caller_launch(pg_ctx* c, int max_iters) {
     // iteration reads them again, and a window's wavefronts wait on each other's memory latency
     int stage = 0;
     {
-        int64_t stage_max = 16384;
-        if (const char* k = std::getenv("PG_EM_STAGE_MAX")) stage_max = std::atoll(k);      // experiments
+        const int64_t stage_max = c->em_stage_max;
         const int64_t room = ((int64_t)152 * 1024 - (int64_t)lds) / (int64_t)sizeof(double);   // static LDS and rounding need the rest
         const int64_t cap = std::min(stage_max, room);
         if (cap > 0) { stage = (int)std::min<int64_t>(c->max_win_full, cap); lds += (size_t)stage * sizeof(double); }
@@ -804,12 +868,13 @@ int pg_caller_launch(pg_ctx* c, int max_iters) {
     // Kernel choice: windows of at most 8 haplotypes take one wavefront each; if every window's matrices fit
     // the LDS staging area, one workgroup per window iterates on them there; otherwise every iteration is a
     // launch pair over (window, individual) workgroups, so that the whole chip streams the matrices.
-    // PG_EM_KERNEL = small | big | multi forces one of them (experiments, tests).
-    const char* force = std::getenv("PG_EM_KERNEL");
+    // pg_set_option("em_kernel", small | big | multi) forces one of them (tests, measurements).
     int path = n_max <= 8 ? 0 : (c->max_win_full > (int64_t)stage && c->max_win_inds <= 65535 ? 2 : 1);
-    if (force && force[0] == 'b') path = 1;
-    if (force && force[0] == 'm') path = 2;
-    if (force && force[0] == 's' && n_max <= 8) path = 0;
+    if (c->em_kernel == 1) path = 1;
+    if (c->em_kernel == 2) path = 2;
+    if (c->em_kernel == 0 && n_max <= 8) path = 0;
+    if (path == 2 && c->max_win_inds > 65535)
+        return fail(c, PG_ERR_UNSUPPORTED, "the launch-pair EM path takes at most 65535 individuals per window");
     if (path == 0) {
         hipLaunchKernelGGL(pg::k_em_small, dim3((c->n_windows + 3) / 4), dim3(256), 0, c->stream,
                            c->d_wins.p, c->n_windows, c->d_ioff.p, c->d_full.p, max_iters,
@@ -837,8 +902,9 @@ int pg_caller_launch(pg_ctx* c, int max_iters) {
         // pinned host memory; the host reads the answer of block b only after it has queued block b + 1, so the
         // device never waits for the host (a converged window's workgroups return at once: the one block that
         // may be queued in vain costs a few empty launches).
-        if (!c->h_active) PG_HIP(c, hipHostMalloc((void**)&c->h_active, 2 * sizeof(int32_t), hipHostMallocDefault));
         c->h_active[0] = c->h_active[1] = c->n_windows;
+        const size_t lds_update = (size_t)((c->max_win_inds + 15) & ~15);
+        PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_em_update), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_update));
         const int n_blocks = (max_iters + 7) / 8;
         for (int b = 0; b < n_blocks; ++b) {
             if (b >= 2) {                                       // the answer of block b - 2
@@ -847,7 +913,7 @@ int pg_caller_launch(pg_ctx* c, int max_iters) {
             }
             for (int it = 8 * b; it < std::min(max_iters, 8 * b + 8); ++it) {
                 hipLaunchKernelGGL(pg::k_em_step, dim3(c->n_windows, c->max_win_inds), dim3(step_threads), lds_step, c->stream, c->d_wins.p, c->d_ioff.p, c->d_full.p, S, n_max);
-                hipLaunchKernelGGL(pg::k_em_update, dim3(c->n_windows), dim3(256), (size_t)((c->max_win_inds + 15) & ~15), c->stream, c->d_wins.p, c->d_ioff.p, S, max_iters);
+                hipLaunchKernelGGL(pg::k_em_update, dim3(c->n_windows), dim3(256), lds_update, c->stream, c->d_wins.p, c->d_ioff.p, S, max_iters);
             }
             PG_HIP(c, hipMemcpyAsync(&c->h_active[b & 1], S.active, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
             PG_HIP(c, hipEventRecord(c->ev_block[b & 1], c->stream));

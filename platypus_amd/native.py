@@ -26,6 +26,7 @@ SYMBOLS = {
     "pg_ctx_destroy": (C.c_int, [C.c_void_p]),
     "pg_last_error_string": (C.c_char_p, [C.c_void_p]),
     "pg_set_params": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_int]),
+    "pg_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
     "pg_haps_upload": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _i64p, _i32p, _i32p]),
     "pg_reads_upload": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _i64p, _i32p, _i32p]),
     "pg_pairs_upload": (C.c_int, [C.c_void_p, C.c_int64, _i32p, _i32p]),
@@ -108,6 +109,10 @@ class AlignContext(object):
         if table is None:
             table = b"NKJHFA=854210/.-,,+**))((('''&&&%%%$$$$#####\"\"\"\"\""
         self._check(LIB.pg_set_params(self._h, gapextend, nucprior, table, len(table)))
+
+    def set_option(self, name, value):
+        """kernel-choice overrides for tests and measurements (include/platgpu.h: pg_set_option)"""
+        self._check(LIB.pg_set_option(self._h, name.encode(), str(value).encode()))
 
     def upload_haps(self, seq, off, start_pos, var_seq_len):
         seq = _arr(seq, np.uint8); off = _arr(off, np.int64)

@@ -11,6 +11,7 @@ cdef extern from "platgpu.h":
     int pg_ctx_destroy(pg_ctx* ctx)
     const char* pg_last_error_string(const pg_ctx* ctx)
     int pg_set_params(pg_ctx* ctx, int gapextend, int nucprior, const char* table, int table_len)
+    int pg_set_option(pg_ctx* ctx, const char* name, const char* value)
     int pg_haps_upload(pg_ctx* ctx, int n, const char* seq, const int64_t* offsets,
                        const int32_t* start_pos, const int32_t* var_seq_len)
     int pg_reads_upload(pg_ctx* ctx, int n, const char* seq, const char* qual, const int64_t* offsets,

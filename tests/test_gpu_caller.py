@@ -25,7 +25,7 @@ def split_reads(rng, n_reads, n_ind, empty=None):
     return off
 
 
-def run_case(n_windows, H, R, n_ind, seed, indel_frac=0.3, empty=None, read_len=60, hap_len=300):
+def run_case(n_windows, H, R, n_ind, seed, indel_frac=0.3, empty=None, read_len=60, hap_len=300, options=()):
     from platypus_amd import native
     from oracle import pyoracle as po
     rng = np.random.default_rng(seed)
@@ -33,6 +33,8 @@ def run_case(n_windows, H, R, n_ind, seed, indel_frac=0.3, empty=None, read_len=
                          hap_len=hap_len, indel_hap_frac=indel_frac, seed=seed)
     ctx = native.AlignContext(0)
     try:
+        for name, value in options:
+            ctx.set_option(name, value)
         ctx.upload_batch(b)
         ctx.launch()
         offs = [split_reads(rng, R, n_ind, empty if (w % 3 == 0) else None) for w in range(n_windows)]
@@ -137,7 +139,7 @@ def test_window_errors():
         ctx.close()
 
 
-def test_small_window_kernel_equals_general_kernel(monkeypatch):
+def test_small_window_kernel_equals_general_kernel():
     """Windows of at most 8 haplotypes take a one-wavefront-per-window kernel; its sums have the
     shape of the general kernel's, so both return the same doubles."""
     from platypus_amd import native
@@ -148,9 +150,9 @@ def test_small_window_kernel_equals_general_kernel(monkeypatch):
     offs = np.concatenate([split_reads(rng, R, n_ind, 1 if w % 4 == 0 else None) for w in range(nw)])
     out = {}
     for which in ("small", "big"):
-        monkeypatch.setenv("PG_EM_KERNEL", which)
         ctx = native.AlignContext(0)
         try:
+            ctx.set_option("em_kernel", which)
             ctx.upload_batch(b)
             ctx.launch()
             ctx.upload_windows([H] * nw, [n_ind] * nw, np.arange(nw, dtype=np.int64) * H * R, offs)
@@ -163,15 +165,14 @@ def test_small_window_kernel_equals_general_kernel(monkeypatch):
 
 
 @pytest.mark.parametrize("which", ["big", "multi"])
-def test_em_kernel_paths_against_checker(monkeypatch, which):
+def test_em_kernel_paths_against_checker(which):
     """the one-workgroup-per-window kernel and the launch-pair-per-iteration path, each forced"""
-    monkeypatch.setenv("PG_EM_KERNEL", which)
-    run_case(n_windows=5, H=40, R=120, n_ind=9, seed=41, indel_frac=0.2, empty=2)
-    run_case(n_windows=7, H=5, R=40, n_ind=3, seed=42)
-    monkeypatch.setenv("PG_EM_KERNEL", which)
+    opt = [("em_kernel", which)]
+    run_case(n_windows=5, H=40, R=120, n_ind=9, seed=41, indel_frac=0.2, empty=2, options=opt)
+    run_case(n_windows=7, H=5, R=40, n_ind=3, seed=42, options=opt)
 
 
-def test_em_iteration_cap(monkeypatch):
+def test_em_iteration_cap():
     """max_iters is honoured by every path (the reference's default is 100, cpopulation.pyx:741)"""
     from platypus_amd import native
     from oracle import pyoracle as po
@@ -179,9 +180,9 @@ def test_em_iteration_cap(monkeypatch):
     b = synth.make_batch(n_windows=nw, haps_per_window=H, reads_per_window=R, read_len=50, hap_len=260, seed=43)
     off = np.linspace(0, R, n_ind + 1).astype(np.int32)
     for which in ("big", "multi"):
-        monkeypatch.setenv("PG_EM_KERNEL", which)
         ctx = native.AlignContext(0)
         try:
+            ctx.set_option("em_kernel", which)
             ctx.upload_batch(b)
             ctx.launch()
             ctx.upload_windows([H] * nw, [n_ind] * nw, np.arange(nw, dtype=np.int64) * H * R, np.tile(off, nw))
@@ -200,9 +201,9 @@ def test_em_iteration_cap(monkeypatch):
 
 
 @pytest.mark.parametrize("which", ["cell", "tile"])
-def test_genotype_likelihood_kernels(monkeypatch, which):
+def test_genotype_likelihood_kernels(which):
     """one thread per cell from global memory, and the LDS-tiled kernel (incl. several read chunks per individual)"""
-    monkeypatch.setenv("PG_GL_KERNEL", which)
-    run_case(n_windows=2, H=257, R=60, n_ind=2, seed=51, indel_frac=0.1, read_len=40, hap_len=200)
-    run_case(n_windows=9, H=4, R=33, n_ind=3, seed=52, empty=0)
-    run_case(n_windows=3, H=30, R=90, n_ind=4, seed=53, indel_frac=0.2)
+    opt = [("gl_kernel", which)]
+    run_case(n_windows=2, H=257, R=60, n_ind=2, seed=51, indel_frac=0.1, read_len=40, hap_len=200, options=opt)
+    run_case(n_windows=9, H=4, R=33, n_ind=3, seed=52, empty=0, options=opt)
+    run_case(n_windows=3, H=30, R=90, n_ind=4, seed=53, indel_frac=0.2, options=opt)
