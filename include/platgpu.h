@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 2
+#define PG_ABI_VERSION 3
 
 enum {
     PG_OK = 0,
@@ -155,6 +155,32 @@ int pg_results_fetch(pg_ctx *ctx, int32_t *score, int32_t *anchor, double *likel
 /* upload pairs + launch + sync + fetch in one call */
 int pg_align_pairs(pg_ctx *ctx, int64_t n_pairs, const int32_t *hap_idx, const int32_t *read_idx,
                    int32_t *score, int32_t *anchor, double *likelihood);
+
+/*
+ * pg_align_pairs for callers that cannot allocate device memory: code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc.  It has
+ * no counterpart in the reference.  Same computation and results as
+ * pg_align_pairs on the uploaded haplotypes and reads, but
+ *   - the pair indices and the three outputs are DEVICE pointers of the caller
+ *     (n_pairs elements each; d_likelihood may be NULL),
+ *   - every intermediate array (vote records, slot order, wavefront descriptors,
+ *     anchors, counters) lives in one fixed device array of about 7 MiB that
+ *     each GPU the library runs on holds until the process ends, so the call
+ *     makes no hipMalloc / hipFree and no allocating library call,
+ *   - at most PG_NOALLOC_MAX_PAIRS pairs per call and at most
+ *     PG_NOALLOC_MAX_INDEL_HAPS haplotypes with var_seq_len != 0 in the uploaded
+ *     batch; more is refused with PG_ERR_UNSUPPORTED.
+ * The call returns after the results are complete (it waits for the context's
+ * stream).  All contexts of a GPU share that GPU's array: two calls that overlap
+ * on one GPU (two host threads, two contexts) race and must be serialised by the
+ * caller.  The results of pg_align_launch and the pair list of pg_pairs_upload
+ * are left untouched.  An index outside the uploaded batches gives
+ * PG_ERR_INVALID and no output is written.
+ */
+#define PG_NOALLOC_MAX_PAIRS 262144
+#define PG_NOALLOC_MAX_INDEL_HAPS 65536
+int pg_align_pairs_noalloc(pg_ctx *ctx, int64_t n_pairs, const int32_t *d_hap_idx, const int32_t *d_read_idx,
+                           int32_t *d_score, int32_t *d_anchor, double *d_likelihood);
 
 /*
  * hash_sequence of the reference on its own (platypus/calign.pyx:99-123): the

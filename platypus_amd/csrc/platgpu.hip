@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -39,8 +40,55 @@ struct DevBuf {
 
 }  // namespace
 
+// ---- fixed device scratch of pg_align_pairs_noalloc -------------------------------
+// The work arrays of one pair-list preparation (pg::PairWork) at their largest supported
+// size, laid out at fixed offsets of one device array that every GPU the library runs on
+// holds until the process ends.  Host code never uses the array's name as an address: its
+// address on a device is asked for once (scratch_on_device) and kept per device.
+namespace {
+constexpr size_t kNaPairs = PG_NOALLOC_MAX_PAIRS;
+constexpr size_t kNaVoteHaps = PG_NOALLOC_MAX_INDEL_HAPS;
+constexpr size_t kNaLen = 16384 + 2;                               // read lengths 0..16384 (pg_ctx_create's limit) + total
+constexpr size_t kNaWaves = kNaPairs / 64 + 16384 + 2;             // wavefront bound of a ragged list
+constexpr size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+constexpr size_t kNaOffStatus = 0;
+constexpr size_t kNaOffHapCnt = kNaOffStatus + up256(pg::ST_WORDS * 4);
+constexpr size_t kNaOffHapCur = kNaOffHapCnt + up256((kNaVoteHaps + 1) * 4);
+constexpr size_t kNaOffLen = kNaOffHapCur + up256((kNaVoteHaps + 1) * 4);
+constexpr size_t kNaOffOrder = kNaOffLen + up256(4 * kNaLen * 4);
+constexpr size_t kNaOffWaves = kNaOffOrder + up256(kNaPairs * 4);
+constexpr size_t kNaOffRecs = kNaOffWaves + up256(kNaWaves * sizeof(pg::WaveDesc));
+constexpr size_t kNaOffAnchor = kNaOffRecs + up256(kNaPairs * sizeof(pg::VoteRec));
+constexpr size_t kNaOffNFlag = kNaOffAnchor + up256(kNaPairs * 4);
+constexpr size_t kNaBytes = kNaOffNFlag + up256(kNaWaves + 64);
+constexpr int kMaxDevices = 64;
+}  // namespace
+
+static __device__ __align__(256) unsigned char scratch[kNaBytes];
+
+namespace {
+std::mutex g_scratch_mutex;
+unsigned char* g_scratch_ptr[kMaxDevices] = {};
+
+// Device address of `scratch` on `device`, which must be the current device.  Every GPU holds its
+// own copy of the array at its own address.
+hipError_t scratch_on_device(int device, unsigned char** out) {
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        g_scratch_ptr[device] = static_cast<unsigned char*>(p);
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
+}  // namespace
+
 struct pg_ctx {
     int device = 0;
+    unsigned char* scratch_ptr = nullptr;   // device address of the fixed scratch array on this context's GPU
     int max_read_len = 512;
     hipStream_t stream = nullptr;
     hipEvent_t ev[2 * PG_K_COUNT] = {};
@@ -327,6 +375,13 @@ int pg_ctx_create(int device_ordinal, int max_read_len, pg_ctx** out) {
     if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
         delete c;
         return fail(nullptr, PG_ERR_HIP, "cannot create a stream on device %d", device_ordinal);
+    }
+    {
+        hipError_t e = scratch_on_device(device_ordinal, &c->scratch_ptr);     // the device is current here
+        if (e != hipSuccess) {
+            delete c;
+            return fail(nullptr, PG_ERR_HIP, "hipGetSymbolAddress(scratch) failed on device %d: %s", device_ordinal, hipGetErrorString(e));
+        }
     }
     for (auto& e : c->ev)
         if (hipEventCreate(&e) != hipSuccess) { delete c; return fail(nullptr, PG_ERR_HIP, "hipEventCreate failed"); }
@@ -654,6 +709,49 @@ int pg_align_pairs(pg_ctx* c, int64_t np, const int32_t* hap_idx, const int32_t*
     rc = pg_align_launch(c);
     if (rc != PG_OK) return rc;
     return pg_results_fetch(c, score, anchor, like);
+}
+
+int pg_align_pairs_noalloc(pg_ctx* c, int64_t np, const int32_t* d_hap_idx, const int32_t* d_read_idx,
+                           int32_t* d_score, int32_t* d_anchor, double* d_like) {
+    if (!c) return PG_ERR_INVALID;
+    if (np < 0 || (np > 0 && (!d_hap_idx || !d_read_idx || !d_score || !d_anchor)))
+        return fail(c, PG_ERR_INVALID, "pg_align_pairs_noalloc: bad arguments");
+    if (np > (int64_t)kNaPairs)
+        return fail(c, PG_ERR_UNSUPPORTED, "pg_align_pairs_noalloc takes at most %lld pairs per call, not %lld",
+                    (long long)kNaPairs, (long long)np);
+    if (c->n_haps == 0 || c->n_reads == 0)
+        return fail(c, PG_ERR_STATE, "upload haplotypes and reads before pairs");
+    if ((size_t)c->n_vote_haps > kNaVoteHaps)
+        return fail(c, PG_ERR_UNSUPPORTED, "pg_align_pairs_noalloc takes at most %lld indel-bearing haplotypes in the "
+                    "uploaded batch, not %d", (long long)kNaVoteHaps, c->n_vote_haps);
+    if ((size_t)c->max_rlen + 2 > kNaLen)
+        return fail(c, PG_ERR_UNSUPPORTED, "pg_align_pairs_noalloc: reads of %d bases", c->max_rlen);
+    if (np == 0) return PG_OK;
+    PG_HIP(c, hipSetDevice(c->device));
+    unsigned char* base = c->scratch_ptr;              // never the array's name: that is no device address on the host
+    pg::PairWork W;
+    W.status = reinterpret_cast<int32_t*>(base + kNaOffStatus);
+    W.hap_cnt = reinterpret_cast<int32_t*>(base + kNaOffHapCnt);
+    W.hap_cur = reinterpret_cast<int32_t*>(base + kNaOffHapCur);
+    W.len_cnt = reinterpret_cast<int32_t*>(base + kNaOffLen);
+    W.len_slot = W.len_cnt + kNaLen; W.len_wave = W.len_cnt + 2 * kNaLen; W.len_cur = W.len_cnt + 3 * kNaLen;
+    W.order = c->uniform_rlen ? nullptr : reinterpret_cast<int32_t*>(base + kNaOffOrder);
+    W.waves = c->uniform_rlen ? nullptr : reinterpret_cast<pg::WaveDesc*>(base + kNaOffWaves);
+    W.recs = reinterpret_cast<pg::VoteRec*>(base + kNaOffRecs);
+    W.anchor_in = reinterpret_cast<int32_t*>(base + kNaOffAnchor);
+    W.n_flag = base + kNaOffNFlag;
+    // the array keeps the last call's contents: enqueue_prep clears the counters it adds into and
+    // rewrites the status words; every other array is written before it is read
+    int rc = enqueue_prep(c, W, d_hap_idx, d_read_idx, np);
+    if (rc != PG_OK) return rc;
+    rc = enqueue_align(c, W, d_hap_idx, d_read_idx, np, d_score, d_anchor, d_like);
+    if (rc != PG_OK) return rc;
+    PG_HIP(c, hipMemcpyAsync(c->h_status, W.status, pg::ST_WORDS * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    PG_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->h_status[pg::ST_BAD_PAIR] != 0x7fffffff)      // the kernels wrote nothing in that case
+        return fail(c, PG_ERR_INVALID, "pair %d refers to a haplotype or read outside the uploaded batches",
+                    c->h_status[pg::ST_BAD_PAIR]);
+    return PG_OK;
 }
 
 int pg_kernel_time_ms(pg_ctx* c, int which, float* ms) {

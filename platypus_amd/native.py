@@ -16,7 +16,8 @@ PG_OK = 0
 PG_ERR_NO_DEVICE, PG_ERR_INVALID, PG_ERR_HIP, PG_ERR_UNSUPPORTED, PG_ERR_STATE = -1, -2, -3, -4, -5
 PG_SCORE_ASSERT_FAILED = -1
 PG_K_ANCHOR, PG_K_ALIGN, PG_K_GENOTYPE, PG_K_CALLER_SETUP, PG_K_CALLER_EM = 0, 1, 2, 3, 4
-ABI_VERSION = 2
+ABI_VERSION = 3
+NOALLOC_MAX_PAIRS, NOALLOC_MAX_INDEL_HAPS = 262144, 65536      # PG_NOALLOC_MAX_* of include/platgpu.h
 
 # every symbol include/platgpu.h declares: (restype, argtypes)
 _i32p, _i64p, _f64p = C.c_void_p, C.c_void_p, C.c_void_p
@@ -36,6 +37,7 @@ SYMBOLS = {
     "pg_sync": (C.c_int, [C.c_void_p]),
     "pg_results_fetch": (C.c_int, [C.c_void_p, _i32p, _i32p, _f64p]),
     "pg_align_pairs": (C.c_int, [C.c_void_p, C.c_int64, _i32p, _i32p, _i32p, _i32p, _f64p]),
+    "pg_align_pairs_noalloc": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pg_kernel_time_ms": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
     "pg_genotype_loglik": (C.c_int, [C.c_void_p, C.c_int64, _i64p, _i64p, _i32p, _f64p]),
     "pg_hash_sequence": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, _i32p]),
@@ -169,6 +171,10 @@ class AlignContext(object):
             return z, z.copy(), np.empty(0, dtype=np.float64)
         self.launch()
         return self.fetch()
+
+    def align_pairs_noalloc(self, n_pairs, d_hap_idx, d_read_idx, d_score, d_anchor, d_like):
+        """device addresses (integers) of the caller's arrays; see include/platgpu.h"""
+        self._check(LIB.pg_align_pairs_noalloc(self._h, n_pairs, d_hap_idx, d_read_idx, d_score, d_anchor, d_like))
 
     def kernel_ms(self, which=PG_K_ALIGN):
         ms = C.c_float(0)
