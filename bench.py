@@ -27,7 +27,12 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 OPS_PER_CELL = 14          # int16 ALU operations per DP cell of the reference recurrence
-NOMINAL_PEAK = 256 * 4 * 16 * 2 * 2.4e9   # CUs x SIMDs x lanes/clk x 2 packed x 2.4 GHz
+NOMINAL_LANE_RATE = 256 * 4 * 32 * 2.4e9   # CUs x SIMDs x lanes per clock x 2.4 GHz: VALU lane-instructions per second
+LDS_LOOKUP_PEAK = 75e12 / 4                # 4-byte LDS reads per second, all CUs streaming
+# VALU instructions one wavefront of k_align2 executes for reads of L bases: VALU_A + VALU_B * (L + 8)
+VALU_A, VALU_B = 601.0, 165.38
+VALU_SOURCE = ("profiles/r02_valu_insts.csv: SQ_INSTS_VALU / SQ_WAVES of k_align2 at L = 100, 150, 250 "
+               "(18461.4, 26729.4, 43268.9 per wavefront; tools/valu_count.sh)")
 
 
 # Pair streams of the benchmark configurations: (haplotypes/window, reads/window, extra synth arguments, text).
@@ -118,6 +123,14 @@ def end_to_end_leg(kb=2000, coverage=30, copies=32):
         shutil.rmtree(work, ignore_errors=True)
 
 
+def max_over_ranks(value, dist, device):
+    """MAX all-reduce of one float (the elapsed time): the only cross-rank operation of the run"""
+    import torch
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -194,7 +207,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        dt = shard.max_over_ranks(dt, dist, sync_dev)      # the only cross-rank operation of the run
+        dt = max_over_ranks(dt, dist, sync_dev)
 
     cells_per_pair = 16 * (L + 8)
     total_cells = float(n_pairs) * cells_per_pair * world * args.steps
@@ -205,30 +218,56 @@ def main():
             dist.destroy_process_group()
         return
 
-    # ---- roofline of the dominant kernel (k_align) ---------------------------------
+    # ---- roofline of the dominant kernel (k_align2): share of the VALU issue rate ------------------
+    # The kernel is bound by VALU instruction issue (integer DP; no MFMA, 10 % of the HBM rate).
+    #   achieved = VALU instructions the kernel EXECUTES per launch x 64 lanes / its average duration
+    #   peak     = 256 CUs x 4 SIMDs x 32 lanes per clock x 2.4 GHz (a wavefront's VALU instruction issues
+    #              over 2 cycles), and beside it the rate a probe of the kernel's own instruction forms
+    #              (v_add_u16 / v_min_u16) reaches in this process
+    # Executed instructions per wavefront are a property of the shipped binary: VALU_A + VALU_B x (L + 8),
+    # from SQ_INSTS_VALU / SQ_WAVES of k_align2 at L = 100, 150, 250 (profiles/, see VALU_SOURCE).
     k_avg = float(np.mean(k_ms)) * 1e-3
-    algo_ops = float(n_pairs) * cells_per_pair * OPS_PER_CELL       # int16 operations per launch
     score, anchor, like = ctx.fetch()
-    peak = ctx.valu_int16_peak()
-    achieved = algo_ops / k_avg
+    n_waves = (n_pairs + 63) // 64
+    insts_per_wave = VALU_A + VALU_B * (L + 8)
+    lane_instr = float(n_waves) * insts_per_wave * 64.0
+    achieved = lane_instr / k_avg
+    probe = ctx.valu_vop2_rate()
+    pk_peak = ctx.valu_int16_peak()
+    algo_ops = float(n_pairs) * cells_per_pair * OPS_PER_CELL       # int16 operations of the reference recurrence
     traffic, traffic_src = pmc_traffic(n_pairs, L) if args.workload == "wgs" else (None, None)
     roofline = {
-        "bound": "valu_int16",
+        "bound": "valu_issue",
         "kernel": "k_align2",
-        "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "Tops/s",
-        "frac": achieved / peak,
-        "peak_source": "v_pk_add_u16/v_pk_min_i16 issue-rate probe run in this process",
-        "peak_nominal": NOMINAL_PEAK / 1e12,
+        "achieved": achieved / 1e12, "peak": NOMINAL_LANE_RATE / 1e12, "unit": "T lane-instructions/s",
+        "frac": achieved / NOMINAL_LANE_RATE,
+        "peak_source": "256 CUs x 4 SIMDs x 32 lanes/clk x 2.4 GHz",
+        "probe_peak": probe / 1e12, "frac_of_probe": achieved / probe,
+        "probe_source": "v_add_u16/v_min_u16 issue-rate probe run in this process",
+        "valu_insts_per_wave": insts_per_wave, "valu_insts_source": VALU_SOURCE,
         "kernel_ms": k_avg * 1e3, "anchor_kernel_ms": float(np.mean(v_ms)),
         "kernel_gcups": float(n_pairs) * cells_per_pair / k_avg / 1e9,
+        # the survey's convention, kept for comparison: 14 int16 operations per cell of the reference
+        # recurrence over the packed-int16 probe rate (the kernel needs fewer instructions per cell than
+        # that, so this is not a fraction of anything the hardware limits)
+        "algorithmic_ops_per_s": algo_ops / k_avg / 1e12, "packed_int16_probe": pk_peak / 1e12,
+        "algorithmic_frac": algo_ops / k_avg / pk_peak,
         "hbm_algorithmic_gbps": float(n_pairs) * (2 * L + 24) / k_avg / 1e9,
         "hbm_peak_gbps": 8000.0,
-        # share of the VALU issue rate: executed VALU instructions (173 per DP iteration, 64 lanes;
-        # count from the shipped ISA and PMC SQ_INSTS_VALU) over 128 lanes/clk/CU x 256 CUs x 2.36 GHz
-        "issue_frac": (float(n_pairs) / 64 * (L + 8) * 173 * 64 / k_avg) / (128 * 256 * 2.36e9),
-        # HBM bytes per launch (PMC, 2 x FETCH_SIZE + WRITE_SIZE) beside the algorithmic bytes per launch
-        "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
         "hbm_algorithmic_bytes": float(n_pairs) * (2 * L + 24),
+        # HBM bytes per launch from the counter passes of a committed profile (not measured in this run)
+        "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+    }
+    # the anchoring kernel in front of it (k_vote4) is bound by LDS look-up latency / issue: one table
+    # look-up per 7-mer of every read of a pair on an indel-bearing haplotype
+    n_vote_pairs = int((batch["hap_varlen"][batch["pair_hap"]] != 0).sum())
+    v_avg = float(np.mean(v_ms)) * 1e-3
+    lookups = float(n_vote_pairs) * max(0, L - 7)
+    roofline_anchor = {
+        "bound": "lds_lookup", "kernel": "k_vote4", "kernel_ms": v_avg * 1e3, "pairs": n_vote_pairs,
+        "achieved": lookups / v_avg / 1e12 if v_avg > 0 else None, "peak": LDS_LOOKUP_PEAK / 1e12,
+        "unit": "T look-ups/s", "frac": lookups / v_avg / LDS_LOOKUP_PEAK if v_avg > 0 else None,
+        "peak_source": "ds_read_b32 aggregate of the chip, 75 TB/s / 4 B",
     }
 
     # ---- the consumer of the likelihood matrix (genotype likelihoods + EM per window), not part of
@@ -292,6 +331,7 @@ def main():
                    "parallelism": "region shards, %d process(es), no collective" % world},
         "pairs_per_s": float(n_pairs) * world * args.steps / dt,
         "roofline": roofline,
+        "roofline_anchor": roofline_anchor,
         "cpu_baseline": cpu,
         "caller_stage": caller,
         "end_to_end": e2e,

@@ -300,6 +300,15 @@ int pg_variant_posteriors(pg_ctx *ctx, int n_vars, const int32_t *var_window,
  */
 int pg_valu_int16_peak(pg_ctx *ctx, double *ops_per_second);
 
+/*
+ * Measured issue rate of the instruction forms the alignment kernel executes
+ * (v_add_u16 / v_min_u16, VGPR operands), in lane-instructions per second
+ * (one instruction of one wavefront = 64).  The denominator of the share of
+ * the VALU issue rate the kernel reaches.  No counterpart in the reference.
+ * Invalidates the results of the last launch.
+ */
+int pg_valu_vop2_rate(pg_ctx *ctx, double *lane_instructions_per_second);
+
 #ifdef __cplusplus
 }
 #endif

@@ -496,4 +496,32 @@ __global__ __launch_bounds__(256) void k_pk_rate(uint32_t* __restrict__ out, int
     out[blockIdx.x * 256 + threadIdx.x] = x;
 }
 
+// ---------------------------------------------------------------------------
+// k_vop2_rate: issue-rate probe for the instruction forms the DP kernel executes,
+// the 16-bit VOP2 instructions v_add_u16 / v_min_u16 with VGPR operands only.
+// 16 independent chains per lane; the 16 additions are issued before the 16 minima
+// that consume them, so no instruction reads a result still in flight.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_vop2_rate(uint32_t* __restrict__ out, int iters, uint32_t b, uint32_t c)
+{
+    uint32_t a[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = threadIdx.x * 3u + i;
+    uint32_t vb = b, vc = c;
+    asm volatile("" : "+v"(vb), "+v"(vc));
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) asm volatile("v_add_u16 %0, %0, %1" : "+v"(a[i]) : "v"(vb));
+#pragma unroll
+            for (int i = 0; i < 16; ++i) asm volatile("v_min_u16 %0, %0, %1" : "+v"(a[i]) : "v"(vc));
+        }
+    }
+    uint32_t x = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x ^= a[i];
+    out[blockIdx.x * 256 + threadIdx.x] = x;
+}
+
 }  // namespace pg

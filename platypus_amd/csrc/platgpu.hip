@@ -1074,8 +1074,13 @@ int pg_variant_posteriors(pg_ctx* c, int nv, const int32_t* var_window, const ui
     return PG_OK;
 }
 
-int pg_valu_int16_peak(pg_ctx* c, double* ops_per_second) {
-    if (!c || !ops_per_second) return PG_ERR_INVALID;
+}  // extern "C"
+
+namespace {
+// best of three timed launches of an issue-rate probe (the first, untimed, warms up); instructions per lane
+// and launch = iters * 8 * 16 * 2
+template <typename K>
+int time_rate_probe(pg_ctx* c, K kernel, double* lane_instr_per_second) {
     PG_HIP(c, hipSetDevice(c->device));
     const int blocks = 256 * 8, iters = 4096;      // 8 workgroups of 4 wavefronts per CU
     PG_HIP(c, c->d_score.reserve((size_t)blocks * 256));
@@ -1084,9 +1089,9 @@ int pg_valu_int16_peak(pg_ctx* c, double* ops_per_second) {
     PG_HIP(c, hipEventCreate(&e0));
     PG_HIP(c, hipEventCreate(&e1));
     float best = 1e30f;
-    for (int rep = 0; rep < 4; ++rep) {            // first repetition warms up
+    for (int rep = 0; rep < 4; ++rep) {
         PG_HIP(c, hipEventRecord(e0, c->stream));
-        hipLaunchKernelGGL(pg::k_pk_rate, dim3(blocks), dim3(256), 0, c->stream, out, iters, 0x00030005u, 0x7ff07ff1u);
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, c->stream, out, iters, 0x00030005u, 0x7ff07ff1u);
         PG_HIP(c, hipEventRecord(e1, c->stream));
         PG_HIP(c, hipEventSynchronize(e1));
         float ms = 0;
@@ -1096,10 +1101,24 @@ int pg_valu_int16_peak(pg_ctx* c, double* ops_per_second) {
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     c->launched = false;                           // the probe used the score buffer
-    // per lane: iters * 8 * 16 chain steps * 2 instructions * 2 int16 operations
-    const double ops = (double)blocks * 256.0 * iters * 8.0 * 16.0 * 2.0 * 2.0;
-    *ops_per_second = ops / (best * 1e-3);
+    *lane_instr_per_second = (double)blocks * 256.0 * iters * 8.0 * 16.0 * 2.0 / (best * 1e-3);
     return PG_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int pg_valu_int16_peak(pg_ctx* c, double* ops_per_second) {
+    if (!c || !ops_per_second) return PG_ERR_INVALID;
+    double rate = 0;
+    int rc = time_rate_probe(c, pg::k_pk_rate, &rate);
+    *ops_per_second = 2.0 * rate;                  // one packed instruction on one lane = 2 int16 operations
+    return rc;
+}
+
+int pg_valu_vop2_rate(pg_ctx* c, double* lane_instructions_per_second) {
+    if (!c || !lane_instructions_per_second) return PG_ERR_INVALID;
+    return time_rate_probe(c, pg::k_vop2_rate, lane_instructions_per_second);
 }
 
 }  // extern "C"

@@ -48,6 +48,7 @@ SYMBOLS = {
     "pg_caller_fetch": (C.c_int, [C.c_void_p, _f64p, _i32p, _f64p, _i32p, _f64p, _f64p]),
     "pg_variant_posteriors": (C.c_int, [C.c_void_p, C.c_int, _i32p, C.c_void_p, _f64p, _f64p]),
     "pg_valu_int16_peak": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "pg_valu_vop2_rate": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
 }
 
 
@@ -184,6 +185,11 @@ class AlignContext(object):
     def valu_int16_peak(self):
         v = C.c_double(0)
         self._check(LIB.pg_valu_int16_peak(self._h, C.byref(v)))
+        return v.value
+
+    def valu_vop2_rate(self):
+        v = C.c_double(0)
+        self._check(LIB.pg_valu_vop2_rate(self._h, C.byref(v)))
         return v.value
 
     def genotype_loglik(self, base1, base2, n_reads):

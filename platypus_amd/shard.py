@@ -6,8 +6,9 @@ chromosome into chunks of ``processRegionSize`` (platypus/bamfileutils.pyx:248-2
 temporary VCF (platypus/runner.py:119-135), and the parent concatenates the
 files sorted by chromosome name, then start (platypus/runner.py:19-30,137-165).
 Workers exchange nothing.  Here the workers are GPU ranks: the same chunks,
-dealt to ranks by estimated work, the same merge order on the host.  The only
-thing ranks ever reduce is a timing (``max_over_ranks``).
+dealt to ranks by estimated work, the same merge order on the host.  Ranks
+exchange nothing here either (a benchmark that wants the slowest rank's time
+reduces it itself).
 """
 import functools
 import os
@@ -83,13 +84,3 @@ def rank_info():
     """(rank, world_size, local_rank) from the torchrun environment."""
     return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
             int(os.environ.get("LOCAL_RANK", "0")))
-
-
-def max_over_ranks(value, dist=None, device=None):
-    """MAX all-reduce of one float (a timing); identity without a process group."""
-    if dist is None or not dist.is_initialized():
-        return float(value)
-    import torch
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device or "cpu")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t.item())

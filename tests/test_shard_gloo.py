@@ -43,6 +43,7 @@ import os, sys, json, time
 sys.path.insert(0, %(root)r)
 import torch.distributed as dist
 from platypus_amd import shard
+import bench                                  # the benchmark's own MAX over ranks
 rank, world, _ = shard.rank_info()
 dist.init_process_group("gloo", rank=rank, world_size=world)
 chunks = shard.split_regions([("chr20", None, 3_000_000), ("chr3", None, 900_000)], 500_000)
@@ -50,7 +51,7 @@ mine = shard.assign(chunks, world)[rank]
 # a stand-in for "call variants in my chunks": one body line per chunk
 parts = {shard.region_name(c): ["#header", "%%s\t%%d" %% (c[0], c[1])] for c in mine}
 dist.barrier()
-t = shard.max_over_ranks(0.25 * (rank + 1), dist)
+t = bench.max_over_ranks(0.25 * (rank + 1), dist, "cpu")
 gathered = [None] * world
 dist.all_gather_object(gathered, parts)      # host-side merge of per-shard outputs, not a data-path collective
 if rank == 0:
