@@ -99,3 +99,28 @@ def test_likelihood_formula():
     for sc, mq in [(0, 60), (30, 20), (2048, 0), (5, 255)]:
         pw = math.exp(-0.23025850929940459 * mq)
         assert po.likelihood(sc, mq) == min(1.0, math.exp(-0.23025850929940459 * sc) * (1 - pw) + pw)
+
+
+def test_restatements_under_address_and_ub_sanitizers(golden_dir, tmp_path):
+    """make -C oracle asan: both C restatements built with ASan + UBSan; the driver replays every golden
+    fastAlignmentRoutine call from exact-size heap blocks (a read past either end aborts), then random
+    windows through the hash / vote / likelihood wrapper and the genotype / EM / posterior stage."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle"), "asan"])
+    g = np.load(os.path.join(golden_dir, "align_golden.npz"))
+    len2 = g["len2"].astype(np.int64)
+    o1 = np.concatenate([[0], np.cumsum(len2 + 15)])
+    o2 = np.concatenate([[0], np.cumsum(len2)])
+    path = tmp_path / "golden.bin"
+    with open(path, "wb") as f:
+        f.write(np.int32(len(len2)).tobytes())
+        for i in range(len(len2)):
+            f.write(np.array([len2[i], g["score"][i]], np.int32).tobytes())
+            f.write(g["seq1"][o1[i]:o1[i + 1]].tobytes())
+            f.write(g["seq2"][o2[i]:o2[i + 1]].tobytes())
+            f.write(g["qual"][o2[i]:o2[i + 1]].tobytes())
+    r = subprocess.run([os.path.join(root, "oracle", "_build", "sanitize_driver"), str(path)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout, r.stderr[-2000:])
+    assert "%d golden calls, 0 mismatches" % len(len2) in r.stdout
