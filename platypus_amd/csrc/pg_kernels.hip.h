@@ -92,7 +92,7 @@ struct VoteRec {      // one (read, indel haplotype) pair of k_vote4, built by k
 
 // ---------------------------------------------------------------------------
 // vote_read: one wavefront maps one read against the unique-7-mer table of a
-// haplotype in LDS (16384 x u16: 0 absent, i+1 unique start, 0xffff repeated;
+// haplotype in LDS (16384 x u16: i+1 unique start, 0xffff absent or repeated (0 also reads as absent);
 // platypus/calign.pyx:99-158) in three sweeps over its votes, none of which
 // depends on the order in which lanes reach LDS:
 //   A  atomic +1 on the vote counter of every hit position
@@ -240,19 +240,26 @@ __device__ __forceinline__ int vote_read(const uint16_t* tab, const uint32_t* ro
 // ---------------------------------------------------------------------------
 // k_vote4: the same anchoring with four LANES per read.  The reference's
 // winner, the first position to reach the final maximum count
-// (platypus/calign.pyx:148-155), is decided without counters whenever one
-// position holds more than half of all votes: that position is the only
-// maximum, so it wins whatever the order.  Two candidates are tried: the
-// position named by the first vote among the read's first eight 7-mers and the
-// one named by the last vote among its last eight (a read that carries an indel
-// relative to this haplotype splits its votes between two positions; the
-// larger group is one of these).  The four lanes of a read take its 16-base
-// groups in turn and count the votes for the two candidates -- per 7-mer a
-// shift, a mask, one LDS look-up and a few ALU instructions, an order of
-// magnitude fewer instructions per read than mapping a read with a whole
-// wavefront -- and add their counts with quad shuffles.  Reads in which neither
-// candidate holds a majority (few) are then mapped one by one by the wavefront
-// with the counting sweeps of vote_read.
+// (platypus/calign.pyx:148-155), is decided without counters from the counts of
+// three candidate positions: the one named by the first vote among the read's
+// first eight 7-mers, by the last vote among its last eight, and by the first
+// vote among eight 7-mers from its middle (a read that carries an indel relative
+// to this haplotype splits its votes between two positions, one with an indel of
+// its own on top between three).  With n_k the candidates' counts and rest the
+// votes for any other position (an upper bound of every other count):
+//   max n_k > rest, one candidate holds it    that position is the only maximum and wins
+//                                             whatever the order of the votes
+//   max n_k > rest, several hold it           each reaches the final maximum with its last
+//                                             vote; the reference keeps the position that
+//                                             gets there first (its update needs count >
+//                                             maxcount): the one whose last vote comes earliest
+// Anything else (about one read in a thousand) is mapped by the whole wavefront with
+// the counting sweeps of vote_read.  The four lanes of a read take its 16-base groups
+// in turn -- per 7-mer a shift, a mask, one LDS look-up, a comparison for "votes at all"
+// and one per candidate -- and combine their counts with quad shuffles.
+// Global memory is off the critical path: the words of round r + 1's reads and the
+// records of round r + 2 are requested before round r is counted, and the first two
+// rounds' words are requested before the table is built.
 // LDS: table (32 KiB) | per wavefront: counters u16[cnt_stride] | packed read u32[row_words].
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ int quad_sum(int v) {
@@ -260,8 +267,41 @@ __device__ __forceinline__ int quad_sum(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
     return v;
 }
+__device__ __forceinline__ int quad_max(int v) {
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false));
+    return v;
+}
 
-__global__ __launch_bounds__(256) void k_vote4(const uint32_t* __restrict__ hap2,
+// first 7-mer of the window in which lane `part` of a read's quad looks for its candidate
+__device__ __forceinline__ int vote_window(int part, int nv) {
+    const int s = part == 0 ? 0 : part == 1 ? nv - 8 : nv >> 1;
+    return s > 0 ? s : 0;
+}
+
+// what one lane of a read's quad fetches for a round: the word pairs of its groups part, part + 4,
+// part + 8, part + 12 (reads of up to 263 bases need no more) and the three words that hold the
+// eight 7-mers of its candidate window
+struct VoteWords {
+    uint2 g[4];
+    uint32_t c[3];
+};
+
+__device__ __forceinline__ void vote_fetch(VoteWords& Q, const uint32_t* __restrict__ rw, int part, int nv, int n_groups)
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        Q.g[j] = make_uint2(0, 0);
+        if (part + 4 * j < n_groups) __builtin_memcpy(&Q.g[j], rw + part + 4 * j, 8);
+    }
+    Q.c[0] = Q.c[1] = Q.c[2] = 0;
+    if (part < 3 && nv > 0) __builtin_memcpy(Q.c, rw + (vote_window(part, nv) >> 4), 12);
+}
+
+#ifndef PG_VOTE_ABLATE
+#define PG_VOTE_ABLATE 0      // measurement builds only: 1 stop after the table build, 2 no counting sweeps for undecided reads
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_vote4(const uint32_t* __restrict__ hap2,
                                                const uint32_t* __restrict__ read2,
                                                const VoteHap* __restrict__ vh,
                                                const int32_t* __restrict__ rec_start,
@@ -285,20 +325,25 @@ __global__ __launch_bounds__(256) void k_vote4(const uint32_t* __restrict__ hap2
     const uint32_t* hw = hap2 + H.hap2off;
     const int L = H.len;
 
-    // the first record of every read slot and this thread's first four 7-mers of the haplotype
-    // are fetched before the table is cleared
-    VoteRec rec = {0, 0, 0};
-    if (q0 + slot < q_end) rec = vh_recs[q0 + slot];
+    // records of the first two rounds and this thread's first four 7-mers of the haplotype
+    const VoteRec none = {0, 0, 0};
+    VoteRec rec = q0 + slot < q_end ? vh_recs[q0 + slot] : none;
+    VoteRec rec_next = q0 + n_slots + slot < q_end ? vh_recs[q0 + n_slots + slot] : none;
     const int nk = L - kHashNucs;               // last 7-mer is left out, calign.pyx:114
     uint32_t hk[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) { const int i = tid + m * n_thr; hk[m] = i < nk ? hash7_packed(hw, i) : 0u; }
+    auto votes_of = [&](const VoteRec& r) { return r.rlen > kHashNucs ? r.rlen - kHashNucs : 0; };   // calign.pyx:143
+    // the words of both rounds are on their way while the table is built
+    VoteWords Q, Q_next;
+    vote_fetch(Q, read2 + rec.r2off, part, votes_of(rec), (votes_of(rec) + 15) >> 4);
+    vote_fetch(Q_next, read2 + rec_next.r2off, part, votes_of(rec_next), (votes_of(rec_next) + 15) >> 4);
 
-    {   // table and counters start at zero (platypus/calign.pyx:105)
-        const int total_dw = (kHashSize + n_wav * cnt_stride) / 2;
+    {   // the table starts empty (platypus/calign.pyx:105; "no start" is 0xffff here, as is "repeated"), counters at zero
+        const int tab_dw = kHashSize / 2, total_dw = (kHashSize + n_wav * cnt_stride) / 2;
         uint4* z = reinterpret_cast<uint4*>(lds);
-        for (int i = tid; i < (total_dw >> 2); i += n_thr) z[i] = make_uint4(0, 0, 0, 0);
-        for (int i = (total_dw & ~3) + tid; i < total_dw; i += n_thr) lds[i] = 0;
+        for (int i = tid; i < (tab_dw >> 2); i += n_thr) z[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+        for (int i = tab_dw + tid; i < total_dw; i += n_thr) lds[i] = 0;
     }
     __syncthreads();
 #pragma unroll
@@ -313,80 +358,158 @@ __global__ __launch_bounds__(256) void k_vote4(const uint32_t* __restrict__ hap2
         if (tab[k] != (uint16_t)(i + 1)) tab[k] = 0xffffu;
     }
     __syncthreads();
+    if (PG_VOTE_ABLATE == 1) { if (Q.g[0].x == 0x12345u && Q_next.g[0].x == 0x54321u) anchor[0] = 0; return; }
 
+    const uint8_t* tab_bytes = reinterpret_cast<const uint8_t*>(tab);
     for (int64_t qb = q0; qb < q_end; qb += n_slots) {
         const bool mine = qb + slot < q_end;
-        if (qb > q0) rec = mine ? vh_recs[qb + slot] : VoteRec{0, 0, 0};
-        const int rl = rec.rlen;
-        const int nv = mine && rl > kHashNucs ? rl - kHashNucs : 0;            // calign.pyx:143
+        const int nv = mine ? votes_of(rec) : 0;
         const uint32_t* rw = read2 + rec.r2off;
         const int n_groups = (nv + 15) >> 4;
+        // request for the round after the next
+        const VoteRec rec_after = qb + 2 * (int64_t)n_slots + slot < q_end ? vh_recs[qb + 2 * (int64_t)n_slots + slot] : none;
+        const VoteWords Qc = Q;
+        Q = Q_next;
 
-        // candidates: lane 0 of the quad looks at the first eight 7-mers, lane 1 at the last eight
-        int c = 0x40000000;                                                      // matches no position
-        if (part < 2 && nv > 0) {
-            int pvs[8], idx[8];
+        // candidates: lanes 0, 1, 2 of the quad look at eight 7-mers from the start, the end and the middle
+        int c = 0x40000000 + part;                                               // matches no position
+        {
+            const int s0 = vote_window(part, nv), w0 = s0 >> 4;
+            uint32_t pvs[8];
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
-                idx[t] = part == 0 ? t : nv - 1 - t;
-                const bool in = idx[t] >= 0 && idx[t] < nv;
-                pvs[t] = in ? (int)(int16_t)tab[hash7_packed(rw, in ? idx[t] : 0)] : 0;
+                const int bit = 2 * (s0 + t - 16 * w0);                          // 0 .. 44
+                const uint32_t lo = bit < 32 ? Qc.c[0] : Qc.c[1], hi = bit < 32 ? Qc.c[1] : Qc.c[2];
+                const uint32_t off = (__builtin_amdgcn_alignbit(hi, lo, bit & 31) << 1) & 0x7ffeu;
+                pvs[t] = *reinterpret_cast<const uint16_t*>(tab_bytes + off);
             }
+            int first = c, last = c;
             bool found = false;
 #pragma unroll
-            for (int t = 0; t < 8; ++t)
-                if (!found && pvs[t] > 0) { c = pvs[t] - 1 - idx[t]; found = true; }
+            for (int t = 0; t < 8; ++t) {
+                const bool valid = pvs[t] != 0xffffu && s0 + t < nv && part < 3;
+                const int pos = (int)pvs[t] - 1 - (s0 + t);
+                first = valid && !found ? pos : first;
+                last = valid ? pos : last;
+                found |= valid;
+            }
+            c = part == 1 ? last : first;
         }
         const int c1 = __builtin_amdgcn_update_dpp(0, c, 0x00, 0xf, 0xf, false);   // quad_perm [0,0,0,0]
-        const int c2 = __builtin_amdgcn_update_dpp(0, c, 0x55, 0xf, 0xf, false);   // quad_perm [1,1,1,1]
+        int c2 = __builtin_amdgcn_update_dpp(0, c, 0x55, 0xf, 0xf, false);         // quad_perm [1,1,1,1]
+        int c3 = __builtin_amdgcn_update_dpp(0, c, 0xAA, 0xf, 0xf, false);         // quad_perm [2,2,2,2]
+        if (c2 == c1) c2 = 0x40000001;                                             // every position counted once
+        if (c3 == c1 || c3 == c2) c3 = 0x40000002;
 
-        // counts over this lane's 16-base groups: part, part + 4, ...
-        int total = 0, n1 = 0, n2 = 0;
-        uint2 ww = make_uint2(0, 0);
-        if (part < n_groups) __builtin_memcpy(&ww, rw + part, 8);
-        for (int g = part; g < n_groups; g += 4) {
-            const uint2 w = ww;
-            if (g + 4 < n_groups) __builtin_memcpy(&ww, rw + g + 4, 8);         // next group's words
-            int pv[16];                               // all 16 look-ups first: they are independent
+        // Counts over this lane's 16-base groups: part, part + 4, ...  A vote of 7-mer i for position c is a
+        // table value of c + 1 + i (calign.pyx:144-147).  (An absent or repeated 7-mer reads 0xffff, which
+        // is no c + 1 + i: positions are below 16384.)
+        uint32_t total = 0, n1 = 0, n2 = 0, n3 = 0;
+        const uint32_t e1 = (uint32_t)c1 + 1u, e2 = (uint32_t)c2 + 1u, e3 = (uint32_t)c3 + 1u;
+        auto count_group = [&](const uint2 w, int g, bool partial) {
+            uint32_t pv[16];                          // all 16 look-ups first: they are independent
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const uint32_t hsh = (j == 0 ? w.x : __builtin_amdgcn_alignbit(w.y, w.x, 2 * j)) & 0x3fffu;
-                pv[j] = (int16_t)tab[hsh];
+                const uint32_t off = (j == 0 ? w.x << 1 : __builtin_amdgcn_alignbit(w.y, w.x, 2 * j - 1)) & 0x7ffeu;
+                pv[j] = *reinterpret_cast<const uint16_t*>(tab_bytes + off);
             }
+            const uint32_t g1 = e1 + 16u * (uint32_t)g, g2 = e2 + 16u * (uint32_t)g, g3 = e3 + 16u * (uint32_t)g;
+            const int jmax = nv - 16 * g;             // 7-mers of this group that exist
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const int i = 16 * g + j;
-                const bool valid = pv[j] > 0 && i < nv;              // 0 absent, 0xffff (= -1) repeated
-                const int pos = pv[j] - 1 - i;                       // calign.pyx:144-147
-                total += valid;
-                n1 += valid && pos == c1;
-                n2 += valid && pos == c2;
+                uint32_t v = pv[j];
+                if (partial && j >= jmax) v = 0xffffu;
+                const uint32_t d = v - (uint32_t)j;
+                total += v != 0xffffu;
+                n1 += d == g1;
+                n2 += d == g2;
+                n3 += d == g3;
+            }
+        };
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // all groups of a step are complete for reads of one length, except in the last step
+            const int g = part + 4 * j;
+            const bool have = g < n_groups, partial = have && 16 * g + 16 > nv;
+            if (__any(partial)) {
+                if (have) count_group(Qc.g[j], g, true);
+            } else if (have) {
+                count_group(Qc.g[j], g, false);
             }
         }
-        total = quad_sum(total); n1 = quad_sum(n1); n2 = quad_sum(n2);
+        for (int g = part + 16; g < n_groups; g += 4) {               // reads beyond 263 bases
+            uint2 w;
+            __builtin_memcpy(&w, rw + g, 8);
+            count_group(w, g, true);
+        }
+        total = (uint32_t)quad_sum((int)total); n1 = (uint32_t)quad_sum((int)n1);
+        n2 = (uint32_t)quad_sum((int)n2); n3 = (uint32_t)quad_sum((int)n3);
+        const uint32_t rest = total - n1 - n2 - n3;
+        const uint32_t top = max(n1, max(n2, n3));
         int winner = 0;                                               // calign.pyx:137: nothing votes
-        bool undecided = false;
+        bool undecided = false, tie = false;
         if (total > 0) {
-            if (2 * n1 > total) winner = c1;
-            else if (2 * n2 > total) winner = c2;
-            else undecided = true;
+            if (top > rest) {
+                const int holders = (n1 == top) + (n2 == top) + (n3 == top);
+                winner = n1 == top ? c1 : n2 == top ? c2 : c3;
+                tie = holders > 1;
+                if (tie && n_groups > 16) { tie = false; undecided = true; }
+            } else {
+                undecided = true;
+            }
+        }
+        if (__any(tie)) {
+            // several candidates reach the final maximum: the one whose last vote comes first got there first
+            int last1 = -1, last2 = -1, last3 = -1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int g = part + 4 * j;
+                if (tie && g < n_groups) {
+                    const uint2 w = Qc.g[j];
+                    for (int k = 0; k < 16 && 16 * g + k < nv; ++k) {
+                        const uint32_t off = (k == 0 ? w.x << 1 : __builtin_amdgcn_alignbit(w.y, w.x, 2 * k - 1)) & 0x7ffeu;
+                        const uint32_t v = *reinterpret_cast<const uint16_t*>(tab_bytes + off);
+                        const uint32_t i = 16u * (uint32_t)g + (uint32_t)k;
+                        if (v == e1 + i) last1 = (int)i;
+                        if (v == e2 + i) last2 = (int)i;
+                        if (v == e3 + i) last3 = (int)i;
+                    }
+                }
+            }
+            last1 = quad_max(last1); last2 = quad_max(last2); last3 = quad_max(last3);
+            if (tie) {
+                int best = 0x7fffffff;
+                if (n3 == top) { best = last3; winner = c3; }
+                if (n2 == top && last2 < best) { best = last2; winner = c2; }
+                if (n1 == top && last1 < best) { best = last1; winner = c1; }
+            }
         }
         if (mine && part == 0 && !undecided) anchor[rec.pair] = winner - 8 > 0 ? winner - 8 : 0;   // calign.pyx:67
 
-        // reads without a majority position: the wavefront maps them one at a time
+        // reads these counts do not decide: the wavefront maps them one at a time
         unsigned long long todo = __ballot(undecided && part == 0);
+        if (PG_VOTE_ABLATE == 2) todo = 0;
         while (todo) {
             const int j = __ffsll((long long)todo) - 1;
             todo &= todo - 1;
             const int pair = __builtin_amdgcn_readlane(rec.pair, j);
             const int rlj = __builtin_amdgcn_readlane(rec.rlen, j);
-            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rec.r2off, j);
-            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)rec.r2off >> 32), j);
-            const int64_t r2 = (int64_t)(((uint64_t)hi << 32) | lo);
-            const int nw = (rlj + 15) / 16 + 1;
-            for (int w = lane; w < nw; w += 64) row[w] = read2[r2 + w];
-            __builtin_amdgcn_wave_barrier();
             const int nvj = rlj - kHashNucs;
+            if (nvj <= 256) {
+                // the read's words are in the registers of its four lanes
+                if ((lane >> 2) == (j >> 2)) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (part + 4 * k < n_groups) { row[part + 4 * k] = Qc.g[k].x; row[part + 4 * k + 1] = Qc.g[k].y; }
+                }
+            } else {
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rec.r2off, j);
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)rec.r2off >> 32), j);
+                const int64_t r2 = (int64_t)(((uint64_t)hi << 32) | lo);
+                const int nw = (rlj + 15) / 16 + 1;
+                for (int w = lane; w < nw; w += 64) row[w] = read2[r2 + w];
+            }
+            __builtin_amdgcn_wave_barrier();
             const int n_chunks = nvj > 0 ? (nvj + 63) >> 6 : 0;
             int win;
             if (n_chunks <= 4) win = vote_read<true>(tab, row, cnt16, cnt32, rlj, nvj, n_chunks, lane);
@@ -394,6 +517,11 @@ __global__ __launch_bounds__(256) void k_vote4(const uint32_t* __restrict__ hap2
             if (lane == 0) anchor[pair] = win - 8 > 0 ? win - 8 : 0;
             __builtin_amdgcn_wave_barrier();
         }
+        // rotate: the next round's record is known, its words were requested a round ago; request the words
+        // of the round after it
+        rec = rec_next;
+        rec_next = rec_after;
+        vote_fetch(Q_next, read2 + rec_next.r2off, part, votes_of(rec_next), (votes_of(rec_next) + 15) >> 4);
     }
 }
 
