@@ -65,7 +65,8 @@ const char *pg_last_error_string(const pg_ctx *ctx);
  * Alignment parameters: the arguments platypus/chaplotype.pyx:264 passes down
  * (gapextend 3, nucprior 2, the homopolymer gap-open string of
  * platypus/chaplotype.pyx:37-40, usehomopolgapq = 1).  `table` holds
- * `table_len` phred+33 characters, 1..255 of them.  Defaults are those values.
+ * `table_len` phred+33 characters, 1..128 of them (the reference's has 49).
+ * Defaults are those values.
  */
 int pg_set_params(pg_ctx *ctx, int gapextend, int nucprior, const char *table, int table_len);
 
@@ -93,6 +94,9 @@ int pg_set_option(pg_ctx *ctx, const char *name, const char *value);
  * becomes a per-haplotype run-length array computed once on upload.
  * A haplotype with var_seq_len != 0 must be 15..16383 long (outside that range
  * the reference itself reads out of bounds or fails its own assertions).
+ * Sequence bytes (haplotypes and reads) are compared for equality only, as the
+ * reference does; bytes 1..31 and 33..126 are taken, any other is refused with
+ * PG_ERR_UNSUPPORTED.
  */
 int pg_haps_upload(pg_ctx *ctx, int n, const char *seq, const int64_t *offsets,
                    const int32_t *start_pos, const int32_t *var_seq_len);

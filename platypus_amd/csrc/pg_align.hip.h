@@ -15,8 +15,13 @@
 // bounded by pos_inf + 24*lane), so the same recurrence is run here on the
 // unscaled costs: pos_inf 0x800, gap extend ge, nucleotide prior np, base
 // quality q, 64 for the padding past the read end, 1 for an 'N' column.
-// Bases are kept as (char << 8); a mismatch then gives (s1 ^ s2) >= 256 > q,
-// so  min_u16(s1 ^ s2, q)  is the cost of align.c:158-162 in two instructions.
+// Bases are kept as codes (see SeqCodes): a read base as a 9-bit pattern of constant
+// weight in bits 7..15 plus bit 0 set for everything but 'N', a haplotype column as
+// the complement of its base's pattern -- or, for an 'N' column beyond the first
+// eight, as the single bit 0.  Then  s2 & s1  is 0 for equal bases, >= 128 > q for
+// different ones and 1 for "read base is no 'N', column is", so
+// min_u16(s2 & s1, q)  is the cost of align.c:158-162 AND the 'N' limit of
+// align.c:68,183 in two instructions; haplotypes with 'N's need no other code path.
 //
 // State carried between iterations (8 lanes each, lane k = diagonal 2k / 2k+1):
 //   u1 = min(M1,I1), D1, M2, I2, D2, u2 = min(M2,I2).
@@ -27,8 +32,21 @@
 namespace pg {
 
 constexpr uint32_t kInf = 0x800;      // pos_inf / 4
-constexpr uint32_t kS2Init = 0x00ff;  // read window before the read starts: equals no (char << 8)
-constexpr uint32_t kPadElem = ('0' << 8) | 64;   // align.c:119-120, packed as (char << 8) | quality
+constexpr uint32_t kS2Init = 0xff81;  // read window before the read starts: a code no column matches
+// Elements of the read and haplotype arrays: (quality or run length) << 9 | char << 1, so that
+// `element & 0x1fe` is the byte offset of the char's entry in a table of 16-bit codes.
+constexpr uint32_t kPadElem = (64u << 9) | ('0' << 1);   // align.c:119-120: char '0', cost 256 / 4
+constexpr uint32_t kNElem = 'N' << 1;                    // haplotype padding: 'N', run 0
+constexpr int kMaxRun = 127;                             // run lengths (gap-open table index) kept per element
+
+// Code tables, 256 entries each, indexed by the sequence byte:
+//   read[b]  pattern(b) << 7 | (b != 'N')      pattern = the i-th 9-bit word with four bits set
+//   hap[b]   ~pattern(b) << 7 & 0xff80, but 0x0001 for 'N'   (columns 8.. of a slice, align.c:183)
+//   hap0[b]  ~pattern(b) << 7 & 0xff80 for every b           (columns 0..7: no 'N' discount, align.c:68)
+// 126 patterns exist: bytes 33..126 and 1..31 have one, any other byte is outside the domain (entry 0).
+struct SeqCodes {
+    uint16_t read[256], hap[256], hap0[256];
+};
 
 // 16-bit VOP2 forms, forced: the compiler would otherwise promote to the
 // half-rate 32-bit minimum or pick an SGPR operand.
@@ -60,13 +78,12 @@ __device__ __forceinline__ u16 in_vgpr(uint32_t x) {
 }
 
 struct Align2Args {
-    const uint16_t* hapx;      // per haplotype position: (char << 8) | run length, padded with 'N'
+    const uint16_t* hapx;      // per haplotype position: run length << 9 | char << 1, padded with 'N'
     const int64_t* hap_xoff;   // element offset of each haplotype in hapx
     const int32_t* hap_len;
     const int32_t* hap_start;
     const int32_t* hap_varlen;
-    const uint8_t* hap_has_n;  // 1: the haplotype contains an 'N'
-    const uint16_t* readx;     // per read position: (char << 8) | quality, padded with kPadElem
+    const uint16_t* readx;     // per read position: quality << 9 | char << 1, padded with kPadElem
     const int64_t* read_xoff;  // element offset of each read in readx (multiple of 8)
     const int32_t* read_pos;
     const int32_t* read_mapq;
@@ -77,12 +94,12 @@ struct Align2Args {
     const int32_t* status;     // status words of the pair list's preparation (pg_prep.hip.h)
     const int32_t* anchor_in;
     const uint8_t* tab;        // table[h] - 33, 256 entries
+    const SeqCodes* codes;
     const double* exp_score;
     const double* exp_mapq;
     int32_t* score;
     int32_t* anchor;
     double* like;
-    uint8_t* n_flag;           // per wavefront: 1 = left to the 'N'-aware kernel
     int n_waves;               // uniform batch: wavefronts; ragged batch: an upper bound, the count is in status
     int uniform_len;           // uniform batch: the read length
     int n_pairs;
@@ -107,9 +124,8 @@ __device__ __forceinline__ int align_wave_count(const Align2Args& A) {
 struct Lane2 {
     u16 m1g[8];                      // min(M1, I1, D1) of the even lanes, ready for the next even half-step
     u16 m2[8], i2[8], d2[8], u2[8];  // odd lanes; u2 = min(m2, i2)
-    u16 s1[8], s2[8], q[8];          // rings: haplotype bases, read bases, read qualities
+    u16 s1[8], s2[8], q[8];          // rings: haplotype column codes, read base codes, read qualities
     u16 gP[8], gM[8];                // rings: gap-open + P (for D), gap-open - ge (for I)
-    u16 nq[8];                       // ring: 'N' limit of the haplotype column (HASN only)
     u16 best;
 };
 
@@ -132,29 +148,39 @@ struct Consts2 {
     u16 mge;      // -ge (mod 2^16)
     u16 inf;      // pos_inf
     u16 inf15;    // pos_inf + 15 P
-    u16 nadd;     // 1 - ('N' << 8)  (mod 2^16)
     uint32_t Ps;  // P again, as a scalar
 };
 
+// LDS tables of a workgroup: gap-open cost per run length and the code tables
+struct AlignLds {
+    uint8_t tab[256];
+    uint16_t read[256], hap[256], hap0[256];
+};
+__device__ __forceinline__ u16 code_of(const uint16_t* table, uint32_t elem) {   // table[char of the element]
+    return *reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(table) + (elem & 0x1feu));
+}
+
 // One iteration t (t & 7 == J) of the loop at align.c:106-232.
-//   re  read element of position t, he  haplotype element of slice position t+8
+//   re  read element of position t, rn  of position t + 1, he  haplotype element of slice position t+8
 // EDGE iterations carry the start-up (t < 8, align.c:127-128) and the score
 // pick-up (t >= len2, align.c:134-156,195-217); the others need neither.
-template <int J, bool HASN, bool EDGE>
-__device__ __forceinline__ void dp_iter(Lane2& L, int t, int len2, int e, uint32_t re, uint32_t he,
-                                        const uint8_t* s_tab, const Consts2& C)
+// The code of read position t is already in its ring slot: it was looked up during
+// iteration t - 1, as the code of position t + 1 is looked up here, so that no
+// instruction waits for LDS.
+template <int J, bool EDGE>
+__device__ __forceinline__ void dp_iter(Lane2& L, int t, int len2, int e, uint32_t re, uint32_t rn, uint32_t he,
+                                        const AlignLds& S, const Consts2& C)
 {
     // align.c:111-121: the read window takes position t
-    L.s2[J] = opaque((u16)(re & 0xff00u));
-    L.q[J] = opaque((u16)(re & 0x00ffu));
+    L.q[J] = opaque((u16)(re >> 9));
     if (EDGE && t < 8) {              // align.c:127-128: lane t (== J here) starts at cost 0
         L.m1g[J] = (u16)(2 * J * C.Ps);
         L.m2[J] = L.u2[J] = (u16)((2 * J + 1) * C.Ps);
     }
     // gap-open of slice position t+8 (align.c:85,186): run length cut at the slice end
     const int room = e - 8 - t;
-    const u16 hrun = min16((u16)(he & 0x00ffu), in_vgpr((uint32_t)(room > 0 ? room : 0)));
-    const u16 gnew = s_tab[hrun];
+    const u16 hrun = min16((u16)(he >> 9), in_vgpr((uint32_t)(room > 0 ? room : 0)));
+    const u16 gnew = S.tab[hrun];
 
     // The half-steps are written as stages of eight independent instructions with
     // a scheduling barrier between stages.  On gfx950 a VALU instruction that
@@ -167,19 +193,17 @@ __device__ __forceinline__ void dp_iter(Lane2& L, int t, int len2, int e, uint32
     u16 x[8], y[8], m1[8], i1[8], u1[8], d1n[8], m2g[8];
     PG_STAGE();
 #pragma unroll
-    for (int k = 0; k < 8; ++k) x[k] = (u16)(L.s2[(J - k) & 7] ^ L.s1[(J + k) & 7]);
+    for (int k = 0; k < 8; ++k) x[k] = (u16)(L.s2[(J - k) & 7] & L.s1[(J + k) & 7]);
     PG_STAGE();
+    // align.c:180-187: the haplotype window takes position t+8; its slot was read for the last time
+    // in the stage above, and the odd half-step is far enough away for the look-up to land
+    L.s1[J] = code_of(S.hap, he);
 #pragma unroll
     for (int k = 0; k < 8; ++k) y[k] = add16(L.m2[k], L.gM[(J + 7 - k) & 7]);
     PG_STAGE();
 #pragma unroll
     for (int k = 0; k < 8; ++k) x[k] = min16(x[k], L.q[(J - k) & 7]);
     PG_STAGE();
-    if (HASN) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) x[k] = min16(x[k], L.nq[(J + k) & 7]);
-        PG_STAGE();
-    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) i1[k] = min16(L.i2[k], y[k]);
     PG_STAGE();
@@ -203,12 +227,7 @@ __device__ __forceinline__ void dp_iter(Lane2& L, int t, int len2, int e, uint32
     for (int k = 0; k < 8; ++k) m2g[k] = min16(L.u2[k], L.d2[k]);                // align.c:190
     PG_STAGE();
 
-    // ---- align.c:180-187: haplotype window, N limits and gap-open vector take position t+8 ----
-    L.s1[J] = opaque((u16)(he & 0xff00u));
-    // 'N' limit of the new column: 1 for an 'N', anything above the largest quality otherwise.
-    // (char << 8) + nadd wraps to exactly 1 for 'N' and to at least 0x101 for every other byte;
-    // a compare + select would bring 4-cycle instruction forms into the loop.
-    if (HASN) L.nq[J] = add16(L.s1[J], C.nadd);
+    // ---- align.c:185-187: the gap-open vector takes position t+8 ----
     L.gP[J] = add16(gnew, C.P);
     L.gM[J] = add16(gnew, C.mge);
 
@@ -216,19 +235,16 @@ __device__ __forceinline__ void dp_iter(Lane2& L, int t, int len2, int e, uint32
     if (EDGE && t >= len2) L.best = take_min<1>(L.best, m2g, t - len2, C.Ps);     // align.c:195-217
     PG_STAGE();
 #pragma unroll
-    for (int k = 0; k < 8; ++k) x[k] = (u16)(L.s2[(J - k) & 7] ^ L.s1[(J + 1 + k) & 7]);
+    for (int k = 0; k < 8; ++k) x[k] = (u16)(L.s2[(J - k) & 7] & L.s1[(J + 1 + k) & 7]);
     PG_STAGE();
+    // the slot of read position t - 7 is free now: the code of position t + 1 goes there
+    L.s2[(J + 1) & 7] = code_of(S.read, rn);
 #pragma unroll
     for (int k = 0; k < 8; ++k) y[k] = add16(d1n[k], C.geP);
     PG_STAGE();
 #pragma unroll
     for (int k = 0; k < 8; ++k) x[k] = min16(x[k], L.q[(J - k) & 7]);
     PG_STAGE();
-    if (HASN) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) x[k] = min16(x[k], L.nq[(J + 1 + k) & 7]);
-        PG_STAGE();
-    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) L.d2[k] = add16(u1[k], L.gP[(J + 8 - k) & 7]);
     PG_STAGE();
@@ -268,35 +284,34 @@ __device__ __forceinline__ uint2 load8_unaligned(const uint16_t* p) {
 // positions tb..tb+3 on entry, the high halves are fetched here for tb+4..tb+7,
 // and the low halves are refetched for the next block while the high halves
 // are in use -- every load has four iterations to land.
-template <bool HASN, bool EDGE>
+template <bool EDGE>
 __device__ __forceinline__ void dp_block(Lane2& L, int tb, int iters, int len2, int e,
                                          const uint16_t* rx, const uint16_t* hx8,
-                                         uint2& rlo, uint2& hlo, const uint8_t* s_tab, const Consts2& C)
+                                         uint2& rlo, uint2& hlo, const AlignLds& S, const Consts2& C)
 {
     const uint2 rhi = *reinterpret_cast<const uint2*>(rx + tb + 4);
     const uint2 hhi = load8_unaligned(hx8 + tb + 4);
-#define PG_IT(J, RB, HB)                                                                        \
-    if (!EDGE || tb + J < iters)                                                                \
-        dp_iter<J, HASN, EDGE>(L, tb + J, len2, e, elem4(RB, J & 3), elem4(HB, J & 3), s_tab, C);
-    PG_IT(0, rlo, hlo) PG_IT(1, rlo, hlo) PG_IT(2, rlo, hlo) PG_IT(3, rlo, hlo)
+#define PG_IT(J, RB, RN, HB)                                                                              \
+    if (!EDGE || tb + J < iters)                                                                          \
+        dp_iter<J, EDGE>(L, tb + J, len2, e, elem4(RB, J & 3), elem4(RN, (J + 1) & 3), elem4(HB, J & 3), S, C);
+    PG_IT(0, rlo, rlo, hlo) PG_IT(1, rlo, rlo, hlo) PG_IT(2, rlo, rlo, hlo) PG_IT(3, rlo, rhi, hlo)
     rlo = *reinterpret_cast<const uint2*>(rx + tb + 8);
     hlo = load8_unaligned(hx8 + tb + 8);
-    PG_IT(4, rhi, hhi) PG_IT(5, rhi, hhi) PG_IT(6, rhi, hhi) PG_IT(7, rhi, hhi)
+    PG_IT(4, rhi, rhi, hhi) PG_IT(5, rhi, rhi, hhi) PG_IT(6, rhi, rhi, hhi) PG_IT(7, rhi, rlo, hhi)
 #undef PG_IT
 }
 
-template <bool HASN>
 __device__ __forceinline__ u16 align_pair(const uint16_t* hx, const uint16_t* rx, int len2,
-                                          const uint8_t* s_tab, uint32_t ge_, uint32_t np_)
+                                          const AlignLds& S, uint32_t ge_, uint32_t np_)
 {
     const int len1 = len2 + 15, e = len1 - 1;
     const uint32_t P = ge_ + np_;
     Consts2 C;
     C.geP = in_vgpr(ge_ + P); C.P = in_vgpr(P); C.mge = in_vgpr(0u - ge_);
     C.inf = in_vgpr(kInf); C.inf15 = in_vgpr(kInf + 15 * P); C.Ps = P;
-    C.nadd = in_vgpr(0x10001u - ((uint32_t)'N' << 8));
     Lane2 L;
     const uint2 h0 = load8_unaligned(hx), h1 = load8_unaligned(hx + 4);
+    uint2 rlo = *reinterpret_cast<const uint2*>(rx);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         L.m1g[k] = (u16)(kInf + 2 * k * P);                                  // align.c:53-58
@@ -304,17 +319,17 @@ __device__ __forceinline__ u16 align_pair(const uint16_t* hx, const uint16_t* rx
         L.s2[k] = kS2Init;                                                   // align.c:64
         L.q[k] = 64;                                                         // align.c:65
         const uint32_t he = k < 4 ? elem4(h0, k & 3) : elem4(h1, k & 3);
-        L.s1[k] = (u16)(he & 0xff00u);                                       // align.c:63
-        L.nq[k] = kInf;               // align.c:68: no 'N' discount inside the first 8 columns
+        L.s1[k] = code_of(S.hap0, he);                // align.c:63,68: no 'N' discount inside the first 8 columns
     }
+    L.s2[0] = code_of(S.read, elem4(rlo, 0));         // read position 0, for iteration 0
     // align.c:100 with the window written as a ring: slot j holds the entry that
     // reaches lane k at iteration t when (t + 7 - k) & 7 == j, i.e. slice position 7-j now
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int pos = 7 - j;
-        const uint32_t run = (pos < 4 ? elem4(h0, pos & 3) : elem4(h1, pos & 3)) & 0xffu;
+        const uint32_t run = (pos < 4 ? elem4(h0, pos & 3) : elem4(h1, pos & 3)) >> 9;
         const uint32_t hr = run < (uint32_t)(e - pos) ? run : (uint32_t)(e - pos);
-        const uint32_t g = s_tab[hr];
+        const uint32_t g = S.tab[hr];
         L.gP[j] = (u16)(g + P);
         L.gM[j] = (u16)(g - ge_);
     }
@@ -322,23 +337,17 @@ __device__ __forceinline__ u16 align_pair(const uint16_t* hx, const uint16_t* rx
 
     const int iters = len2 + 8;                                              // align.c:106
     const uint16_t* hx8 = hx + 8;
-    uint2 rlo = *reinterpret_cast<const uint2*>(rx);
     uint2 hlo = load8_unaligned(hx8);
     int tb = 0;
-    dp_block<HASN, true>(L, tb, iters, len2, e, rx, hx8, rlo, hlo, s_tab, C);
+    dp_block<true>(L, tb, iters, len2, e, rx, hx8, rlo, hlo, S, C);
     for (tb = 8; tb + 8 <= len2; tb += 8)
-        dp_block<HASN, false>(L, tb, iters, len2, e, rx, hx8, rlo, hlo, s_tab, C);
+        dp_block<false>(L, tb, iters, len2, e, rx, hx8, rlo, hlo, S, C);
     for (; tb < iters; tb += 8)
-        dp_block<HASN, true>(L, tb, iters, len2, e, rx, hx8, rlo, hlo, s_tab, C);
+        dp_block<true>(L, tb, iters, len2, e, rx, hx8, rlo, hlo, S, C);
     return L.best;
 }
 
-// The fast kernel (no 'N' handling, 128 VGPRs, 4 wavefronts per SIMD) takes every
-// wavefront; one whose pairs may meet an 'N' (the haplotype has one, or the
-// slice reaches the 'N' padding) only raises its flag and leaves.
-// The second kernel takes the flagged ones with the full recurrence.
-template <bool HASN>
-__device__ __forceinline__ void align_wave(const Align2Args& A, int wave, const uint8_t* s_tab)
+__device__ __forceinline__ void align_wave(const Align2Args& A, int wave, const AlignLds& S)
 {
     const int lane = threadIdx.x & 63;
     int w_first = wave * 64, w_count = min(64, A.n_pairs - wave * 64), len2 = A.uniform_len;
@@ -366,16 +375,9 @@ __device__ __forceinline__ void align_wave(const Align2Args& A, int wave, const 
     } else {
         a = a_report = A.anchor_in[pair];
     }
-    if (!HASN) {
-        // an 'N' can only be met if the haplotype has one or the slice reaches the 'N' padding
-        const bool need_n = A.hap_has_n[h] != 0 || a + len1 + 1 > hl;
-        const bool handed_over = __any(need_n);
-        if (lane == 0) A.n_flag[wave] = handed_over ? 1 : 0;
-        if (handed_over) return;
-    }
     const uint16_t* hx = A.hapx + A.hap_xoff[h] + a;
     const uint16_t* rx = A.readx + A.read_xoff[r];
-    const u16 best = align_pair<HASN>(hx, rx, len2, s_tab, (uint32_t)A.ge, (uint32_t)A.np);
+    const u16 best = align_pair(hx, rx, len2, S, (uint32_t)A.ge, (uint32_t)A.np);
 
     if (active) {
         const int sc = failed ? -1 : (int)best;                              // align.c:234
@@ -397,78 +399,58 @@ __device__ __forceinline__ void align_wave(const Align2Args& A, int wave, const 
 // 128 registers: four wavefronts per SIMD
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_align2(const Align2Args A)
 {
-    __shared__ uint8_t s_tab[256];
-    s_tab[threadIdx.x] = A.tab[threadIdx.x];
+    __shared__ AlignLds S;
+    S.tab[threadIdx.x] = A.tab[threadIdx.x];
+    S.read[threadIdx.x] = A.codes->read[threadIdx.x];
+    S.hap[threadIdx.x] = A.codes->hap[threadIdx.x];
+    S.hap0[threadIdx.x] = A.codes->hap0[threadIdx.x];
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256u + threadIdx.x) >> 6));
     if (wave >= align_wave_count(A)) return;
-    align_wave<false>(A, wave, s_tab);
-}
-
-__global__ __launch_bounds__(256) void k_align2n(const Align2Args A)
-{
-    __shared__ uint8_t s_tab[256];
-    s_tab[threadIdx.x] = A.tab[threadIdx.x];
-    __syncthreads();
-    // Same grid as k_align2; a wavefront runs if the previous kernel on this stream
-    // raised its flag.  (A compacted work list costs one atomic per entry on a single
-    // address, which serialises for longer than the listed work takes when most
-    // wavefronts are listed; a persistent grid walking the flags ran 20 % slower
-    // than letting the dispatcher place one short-lived wavefront per entry.)
-    const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256u + threadIdx.x) >> 6));
-    if (wave >= align_wave_count(A) || !A.n_flag[wave]) return;
-    align_wave<true>(A, wave, s_tab);
+    align_wave(A, wave, S);
 }
 
 // ---------------------------------------------------------------------------
 // Upload passes that build the element arrays k_align2 streams.
 // ---------------------------------------------------------------------------
 
-// hapx[xoff[h] + p] = (char << 8) | run for p < len, ('N' << 8) for the padding.
+// hapx[xoff[h] + p] = run << 9 | char << 1 for p < len, 'N' with run 0 for the padding.
 // run = number of following equal bases, an 'N' never extends a run, capped at
 // `cap` (table length - 1): the count of align.c:73-90 before its cut at the
-// slice end.  has_n[h] = 1 if any base is 'N'.
+// slice end.  *bad_byte is set if a base has no code (SeqCodes).
 __global__ __launch_bounds__(256) void k_pack_hapx(const uint8_t* __restrict__ src,
                                                    const int64_t* __restrict__ soff,
                                                    const int64_t* __restrict__ xoff,
-                                                   uint16_t* __restrict__ dst, uint8_t* __restrict__ has_n,
-                                                   int n_haps, int pad, int cap)
+                                                   uint16_t* __restrict__ dst, const SeqCodes* __restrict__ codes,
+                                                   int32_t* __restrict__ bad_byte, int n_haps, int pad, int cap)
 {
-    __shared__ int s_n;
     for (int h = blockIdx.x; h < n_haps; h += gridDim.x) {
-        if (threadIdx.x == 0) s_n = 0;
-        __syncthreads();
         const int64_t s0 = soff[h];
         const int len = (int)(soff[h + 1] - s0);
         const int64_t d0 = xoff[h];
-        bool any_n = false;
+        bool bad = false;
         for (int p = threadIdx.x; p < len + pad; p += blockDim.x) {
             uint32_t c = 'N', r = 0;
             if (p < len) {
                 c = src[s0 + p];
-                if (c != 'N') {
+                bad |= codes->read[c] == 0;
+                if (c != 'N')
                     while ((int)r < cap && p + (int)r + 1 < len && src[s0 + p + r + 1] == c) ++r;
-                } else {
-                    any_n = true;
-                }
             }
-            dst[d0 + p] = (uint16_t)((c << 8) | r);
+            dst[d0 + p] = (uint16_t)((r << 9) | (c << 1));
         }
-        if (any_n) s_n = 1;
-        __syncthreads();
-        if (threadIdx.x == 0) has_n[h] = (uint8_t)s_n;
-        __syncthreads();
+        if (bad) atomicOr(bad_byte, 2);
     }
 }
 
-// readx[xoff[r] + j] = (char << 8) | quality for j < len, kPadElem up to xoff[r+1].
-// *bad_quality is set if any quality byte has its top bit set.
+// readx[xoff[r] + j] = quality << 9 | char << 1 for j < len, kPadElem up to xoff[r+1].
+// *bad is set to 1 if any quality byte has its top bit set, to 2 if a base has no code.
 __global__ __launch_bounds__(256) void k_pack_readx(const uint8_t* __restrict__ seq,
                                                     const uint8_t* __restrict__ qual,
                                                     const int64_t* __restrict__ roff,
                                                     const int64_t* __restrict__ xoff,
-                                                    uint16_t* __restrict__ dst, int n_reads,
-                                                    int32_t* __restrict__ bad_quality)
+                                                    uint16_t* __restrict__ dst, const SeqCodes* __restrict__ codes,
+                                                    int n_reads, int32_t* __restrict__ bad)
 {
     const int wave = (int)((blockIdx.x * 256u + threadIdx.x) >> 6), lane = threadIdx.x & 63;
     const int n_waves = (int)(gridDim.x * 4u);
@@ -478,13 +460,17 @@ __global__ __launch_bounds__(256) void k_pack_readx(const uint8_t* __restrict__ 
         const int64_t d0 = xoff[r];
         const int tot = (int)(xoff[r + 1] - d0);
         uint32_t seen = 0;
+        bool no_code = false;
         for (int j = lane; j < tot; j += 64) {
             const uint32_t q = j < len ? qual[s0 + j] : 0u;
+            const uint32_t c = j < len ? seq[s0 + j] : (uint32_t)'A';
             seen |= q;
-            dst[d0 + j] = j < len ? (uint16_t)(((uint32_t)seq[s0 + j] << 8) | q) : (uint16_t)kPadElem;
+            no_code |= codes->read[c] == 0;
+            dst[d0 + j] = j < len ? (uint16_t)(((q & 0x7fu) << 9) | (c << 1)) : (uint16_t)kPadElem;
         }
         // qualities above 127 are outside the domain (the reference reads them as signed char)
-        if (seen & 0x80u) atomicOr(bad_quality, 1);
+        if (seen & 0x80u) atomicOr(bad, 1);
+        if (no_code) atomicOr(bad, 2);
     }
 }
 

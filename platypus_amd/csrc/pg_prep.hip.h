@@ -45,7 +45,6 @@ struct PairWork {
     WaveDesc* waves;      // [n_pairs / 64 + max_len + 2]                         (ragged batches only)
     VoteRec* recs;        // [n_pairs]
     int32_t* anchor_in;   // [n_pairs]
-    uint8_t* n_flag;      // [wavefront bound]
 };
 
 struct PrepArgs {

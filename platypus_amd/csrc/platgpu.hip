@@ -59,8 +59,7 @@ constexpr size_t kNaOffOrder = kNaOffLen + up256(4 * kNaLen * 4);
 constexpr size_t kNaOffWaves = kNaOffOrder + up256(kNaPairs * 4);
 constexpr size_t kNaOffRecs = kNaOffWaves + up256(kNaWaves * sizeof(pg::WaveDesc));
 constexpr size_t kNaOffAnchor = kNaOffRecs + up256(kNaPairs * sizeof(pg::VoteRec));
-constexpr size_t kNaOffNFlag = kNaOffAnchor + up256(kNaPairs * 4);
-constexpr size_t kNaBytes = kNaOffNFlag + up256(kNaWaves + 64);
+constexpr size_t kNaBytes = kNaOffAnchor + up256(kNaPairs * 4);
 constexpr int kMaxDevices = 64;
 }  // namespace
 
@@ -101,6 +100,7 @@ struct pg_ctx {
     int gapextend = 3, nucprior = 2;
     std::string table;
     DevBuf<uint8_t> d_tab1;              // table[h] - 33
+    DevBuf<pg::SeqCodes> d_codes;        // code tables of the sequence bytes (pg_align.hip.h)
     // kernel-choice overrides of pg_set_option (tests and measurements); 0 / -1 = the library decides
     int vote_waves = 0;                  // "vote_waves": wavefronts per workgroup of the vote kernel
     int lds_pad = 0;                     // "align_lds_pad": extra LDS per workgroup of the DP kernel, lowers its occupancy
@@ -115,7 +115,7 @@ struct pg_ctx {
     int max_hap_len = 0;
     int n_vote_haps = 0;                 // indel-bearing haplotypes of the upload (var_seq_len != 0)
     DevBuf<int32_t> d_hap_vote_ord;      // per haplotype: its number among those, -1 for the others
-    DevBuf<uint8_t> d_hap_raw, d_hap_has_n;
+    DevBuf<uint8_t> d_hap_raw;
     DevBuf<uint16_t> d_hapx;
     DevBuf<uint32_t> d_hap2;            // 2-bit packed bases
     DevBuf<int64_t> d_hap2off;
@@ -138,7 +138,6 @@ struct pg_ctx {
     DevBuf<int32_t> d_pair_hap, d_pair_read, d_order, d_anchor_in;
     DevBuf<int32_t> d_status, d_hap_cnt, d_hap_cur, d_len_work;
     DevBuf<pg::VoteHap> d_vh;            // one per indel-bearing haplotype, made by pg_haps_upload
-    DevBuf<uint8_t> d_n_flag;
     DevBuf<pg::WaveDesc> d_waves;
     DevBuf<pg::VoteRec> d_vh_recs;
     DevBuf<int32_t> d_blk32;             // block descriptors of pg_pairs_blocks
@@ -202,6 +201,26 @@ int upload_params(pg_ctx* c) {
     for (int i = 0; i < 256; ++i) tab1[i] = (uint8_t)((unsigned char)c->table[std::min(i, n - 1)] - '!');
     PG_HIP(c, c->d_tab1.reserve(256));
     PG_HIP(c, hipMemcpyAsync(c->d_tab1.p, tab1, sizeof tab1, hipMemcpyHostToDevice, c->stream));
+    // code tables of pg_align.hip.h: the 126 nine-bit words with four bits set, in ascending order, for the
+    // bytes 33..126 and 1..31 (a NUL would end the reference's strlen, calign.pyx:134); 'N' columns beyond the first eight of a slice match everything at cost 1
+    static pg::SeqCodes codes;
+    {
+        std::memset(&codes, 0, sizeof codes);
+        int next = 0;
+        uint16_t pattern[126];
+        for (uint32_t w = 0; w < 512 && next < 126; ++w)
+            if (__builtin_popcount(w) == 4) pattern[next++] = (uint16_t)w;
+        for (int b = 0; b < 256; ++b) {
+            const int idx = b >= 33 && b <= 126 ? b - 33 : (b >= 1 && b < 32 ? 94 + b : -1);
+            if (idx < 0) continue;
+            const uint16_t pat = (uint16_t)(pattern[idx] << 7);
+            codes.read[b] = (uint16_t)(pat | (b != 'N'));
+            codes.hap0[b] = (uint16_t)(~pat & 0xff80u);
+            codes.hap[b] = b == 'N' ? (uint16_t)1 : codes.hap0[b];
+        }
+    }
+    PG_HIP(c, c->d_codes.reserve(1));
+    PG_HIP(c, hipMemcpyAsync(c->d_codes.p, &codes, sizeof codes, hipMemcpyHostToDevice, c->stream));
     // likelihood factors with the host C library, so the device result is the
     // same double the reference computes (calign.pyx:17,55,63)
     const double mLTOT = -0.23025850929940459;
@@ -264,7 +283,6 @@ int finish_pairs(pg_ctx* c, int64_t np) {
     PG_HIP(c, c->d_hap_cur.reserve((size_t)c->n_vote_haps + 1));
     PG_HIP(c, c->d_vh_recs.reserve(np));
     PG_HIP(c, c->d_anchor_in.reserve(np));
-    PG_HIP(c, c->d_n_flag.reserve((size_t)wb + 64));
     PG_HIP(c, c->d_score.reserve(np));
     PG_HIP(c, c->d_anchor.reserve(np));
     PG_HIP(c, c->d_like.reserve(np));
@@ -279,7 +297,7 @@ int finish_pairs(pg_ctx* c, int64_t np) {
     W.len_cur = c->d_len_work.p + 3 * L;
     W.order = c->uniform_rlen ? nullptr : c->d_order.p;
     W.waves = c->uniform_rlen ? nullptr : c->d_waves.p;
-    W.recs = c->d_vh_recs.p; W.anchor_in = c->d_anchor_in.p; W.n_flag = c->d_n_flag.p;
+    W.recs = c->d_vh_recs.p; W.anchor_in = c->d_anchor_in.p;
     int rc = enqueue_prep(c, W, c->d_pair_hap.p, c->d_pair_read.p, np);
     if (rc != PG_OK) return rc;
     PG_HIP(c, hipMemcpyAsync(c->h_status, W.status, pg::ST_WORDS * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
@@ -318,23 +336,20 @@ int enqueue_align(pg_ctx* c, const pg::PairWork& W, const int32_t* pair_hap, con
     const int n_waves = wave_bound(c, np);
     pg::Align2Args B;
     B.hapx = c->d_hapx.p; B.hap_xoff = c->d_hap_doff.p; B.hap_len = c->d_hap_len.p;
-    B.hap_start = c->d_hap_start.p; B.hap_varlen = c->d_hap_varlen.p; B.hap_has_n = c->d_hap_has_n.p;
+    B.hap_start = c->d_hap_start.p; B.hap_varlen = c->d_hap_varlen.p;
     B.readx = c->d_readx.p; B.read_xoff = c->d_read_xoff.p;
     B.read_pos = c->d_read_pos.p; B.read_mapq = c->d_read_mapq.p;
     B.pair_hap = pair_hap; B.pair_read = pair_read;
     B.order = W.order; B.waves = W.waves; B.status = W.status;
-    B.anchor_in = W.anchor_in; B.tab = c->d_tab1.p;
+    B.anchor_in = W.anchor_in; B.tab = c->d_tab1.p; B.codes = c->d_codes.p;
     B.exp_score = c->d_exp_score.p; B.exp_mapq = c->d_exp_mapq.p;
     B.score = score; B.anchor = anchor; B.like = like;
-    B.n_flag = W.n_flag;
     B.n_waves = n_waves; B.uniform_len = c->max_rlen; B.n_pairs = (int)np;
     B.ge = c->gapextend; B.np = c->nucprior;
     if (c->lds_pad > 0)
         PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_align2), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_pad));
     PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_ALIGN], c->stream));
     hipLaunchKernelGGL(pg::k_align2, dim3((n_waves + 3) / 4), dim3(256), c->lds_pad, c->stream, B);
-    PG_HIP(c, hipGetLastError());
-    hipLaunchKernelGGL(pg::k_align2n, dim3((n_waves + 3) / 4), dim3(256), 0, c->stream, B);
     PG_HIP(c, hipGetLastError());
     PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_ALIGN + 1], c->stream));
     c->ev_valid[PG_K_ALIGN] = true;
@@ -402,7 +417,7 @@ int pg_ctx_destroy(pg_ctx* c) {
     if (!c) return PG_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    c->d_tab1.release(); c->d_hap_has_n.release(); c->d_hapx.release();
+    c->d_tab1.release(); c->d_codes.release(); c->d_hapx.release();
     c->d_readx.release(); c->d_read_xoff.release(); c->d_hap2.release(); c->d_hap2off.release();
     c->d_read2.release(); c->d_read2off.release();
     c->d_exp_score.release(); c->d_exp_mapq.release();
@@ -415,7 +430,7 @@ int pg_ctx_destroy(pg_ctx* c) {
     c->d_vh.release(); c->d_anchor_in.release(); c->d_hap_vote_ord.release(); c->d_read_len.release();
     c->d_status.release(); c->d_hap_cnt.release(); c->d_hap_cur.release(); c->d_len_work.release();
     c->d_blk32.release(); c->d_blk_base.release();
-    c->d_n_flag.release(); c->d_wins.release(); c->d_ioff.release(); c->d_em_iters.release(); c->d_best_gen.release();
+    c->d_wins.release(); c->d_ioff.release(); c->d_em_iters.release(); c->d_best_gen.release();
     c->d_var_win.release(); c->d_cells.release(); c->d_full.release(); c->d_freq.release(); c->d_em_change.release();
     c->d_best_val.release(); c->d_var_prior.release(); c->d_var_out.release(); c->d_var_moff.release(); c->d_win_max.release(); c->d_fprev.release(); c->d_share.release(); c->d_em_done.release(); c->d_share_base.release(); c->d_rows.release(); c->d_cmp_bytes.release(); c->d_cmp_ints.release(); c->d_var_mask.release(); c->d_vh_recs.release(); c->d_waves.release(); c->d_score.release(); c->d_anchor.release(); c->d_like.release();
     c->d_g1.release(); c->d_g2.release(); c->d_gn.release(); c->d_gout.release();
@@ -430,8 +445,8 @@ int pg_ctx_destroy(pg_ctx* c) {
 
 int pg_set_params(pg_ctx* c, int gapextend, int nucprior, const char* table, int table_len) {
     if (!c) return PG_ERR_INVALID;
-    if (!table || table_len < 1 || table_len > 255)
-        return fail(c, PG_ERR_INVALID, "gap-open table must hold 1..255 characters");
+    if (!table || table_len < 1 || table_len > pg::kMaxRun + 1)
+        return fail(c, PG_ERR_INVALID, "gap-open table must hold 1..%d characters", pg::kMaxRun + 1);
     if (gapextend < 0 || gapextend > 64 || nucprior < 0 || nucprior > 64)
         return fail(c, PG_ERR_INVALID, "gapextend/nucprior outside 0..64");
     for (int i = 0; i < table_len; ++i)
@@ -498,7 +513,6 @@ int pg_haps_upload(pg_ctx* c, int n, const char* seq, const int64_t* off,
     doff[n] = total + (int64_t)n * pad;
     PG_HIP(c, c->d_hap_raw.reserve((size_t)total + 16));
     PG_HIP(c, c->d_hapx.reserve((size_t)doff[n] + 64));
-    PG_HIP(c, c->d_hap_has_n.reserve(n));
     PG_HIP(c, c->d_hap_soff.reserve(n + 1));
     PG_HIP(c, c->d_hap_doff.reserve(n + 1));
     PG_HIP(c, c->d_hap_len.reserve(n));
@@ -514,8 +528,10 @@ int pg_haps_upload(pg_ctx* c, int n, const char* seq, const int64_t* off,
     PG_HIP(c, hipMemcpyAsync(c->d_hap_varlen.p, var_seq_len, n * 4, hipMemcpyHostToDevice, c->stream));
     const int cap = (int)c->table.size() - 1;
     const int grid = std::min(n, 65536);
+    PG_HIP(c, c->d_flag.reserve(64));
+    PG_HIP(c, hipMemsetAsync(c->d_flag.p, 0, 64 * sizeof(int32_t), c->stream));
     hipLaunchKernelGGL(pg::k_pack_hapx, dim3(grid), dim3(256), 0, c->stream, c->d_hap_raw.p, c->d_hap_soff.p,
-                       c->d_hap_doff.p, c->d_hapx.p, c->d_hap_has_n.p, n, pad, cap);
+                       c->d_hap_doff.p, c->d_hapx.p, c->d_codes.p, c->d_flag.p, n, pad, cap);
     PG_HIP(c, hipGetLastError());
     std::vector<int64_t> off2(n + 1);
     off2[0] = 0;
@@ -538,7 +554,10 @@ int pg_haps_upload(pg_ctx* c, int n, const char* seq, const int64_t* off,
     PG_HIP(c, hipMemcpyAsync(c->d_hap_vote_ord.p, ord.data(), n * 4, hipMemcpyHostToDevice, c->stream));
     if (!vh.empty())
         PG_HIP(c, hipMemcpyAsync(c->d_vh.p, vh.data(), vh.size() * sizeof(pg::VoteHap), hipMemcpyHostToDevice, c->stream));
+    int32_t bad = 0;
+    PG_HIP(c, hipMemcpyAsync(&bad, c->d_flag.p, sizeof bad, hipMemcpyDeviceToHost, c->stream));
     PG_HIP(c, hipStreamSynchronize(c->stream));   // host vectors above go out of scope
+    if (bad) return fail(c, PG_ERR_UNSUPPORTED, "a haplotype holds a byte outside 1..31, 33..126");
     c->n_vote_haps = (int)vh.size();
     c->max_hap_len = maxlen;
     c->n_haps = n;
@@ -588,7 +607,7 @@ int pg_reads_upload(pg_ctx* c, int n, const char* seq, const char* qual, const i
     PG_HIP(c, hipMemcpyAsync(c->d_read_pos.p, pos, n * 4, hipMemcpyHostToDevice, c->stream));
     PG_HIP(c, hipMemcpyAsync(c->d_read_mapq.p, mapq, n * 4, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(pg::k_pack_readx, dim3(std::min((n + 3) / 4, 65536)), dim3(256), 0, c->stream, c->d_rseq.p,
-                       c->d_rqual.p, c->d_roff.p, c->d_read_xoff.p, c->d_readx.p, n, c->d_flag.p);
+                       c->d_rqual.p, c->d_roff.p, c->d_read_xoff.p, c->d_readx.p, c->d_codes.p, n, c->d_flag.p);
     PG_HIP(c, hipGetLastError());
     std::vector<int64_t> off2(n + 1);
     off2[0] = 0;
@@ -602,7 +621,8 @@ int pg_reads_upload(pg_ctx* c, int n, const char* seq, const char* qual, const i
     int32_t bad = 0;
     PG_HIP(c, hipMemcpyAsync(&bad, c->d_flag.p, sizeof bad, hipMemcpyDeviceToHost, c->stream));
     PG_HIP(c, hipStreamSynchronize(c->stream));
-    if (bad) return fail(c, PG_ERR_UNSUPPORTED, "a base quality above 127 was found");
+    if (bad & 1) return fail(c, PG_ERR_UNSUPPORTED, "a base quality above 127 was found");
+    if (bad & 2) return fail(c, PG_ERR_UNSUPPORTED, "a read holds a byte outside 1..31, 33..126");
     c->max_rlen = maxl;
     c->uniform_rlen = (maxl == minl);
     c->n_reads = n;
@@ -739,7 +759,6 @@ int pg_align_pairs_noalloc(pg_ctx* c, int64_t np, const int32_t* d_hap_idx, cons
     W.waves = c->uniform_rlen ? nullptr : reinterpret_cast<pg::WaveDesc*>(base + kNaOffWaves);
     W.recs = reinterpret_cast<pg::VoteRec*>(base + kNaOffRecs);
     W.anchor_in = reinterpret_cast<int32_t*>(base + kNaOffAnchor);
-    W.n_flag = base + kNaOffNFlag;
     // the array keeps the last call's contents: enqueue_prep clears the counters it adds into and
     // rewrites the status words; every other array is written before it is read
     int rc = enqueue_prep(c, W, d_hap_idx, d_read_idx, np);

@@ -170,6 +170,61 @@ def test_dense_block_and_errors(ctx):
     assert len(s0) == 0 and len(a0) == 0 and len(l0) == 0
 
 
+def test_every_supported_byte_and_the_refused_ones(ctx):
+    """Sequence bytes are compared for equality only (align.c:158-162), whatever they are: IUPAC codes,
+    lower case, '=', digits (the read padding is '0', align.c:119-120), control bytes.  Every byte in
+    1..31 and 33..126 is taken, in reads and haplotypes, on both anchoring paths; the rest is refused."""
+    from platypus_amd import native
+    rng = np.random.default_rng(17)
+    alphabet = np.array(list(range(1, 32)) + list(range(33, 127)), np.uint8)
+    n_h, hl, rl, per = 12, 400, 90, 30
+    haps = [alphabet[rng.integers(0, len(alphabet), hl)] for _ in range(n_h)]
+    for h in haps[:6]:                                           # half of them mostly ACGTN0 with runs
+        h[:] = np.frombuffer(b"ACGTN0acgt=", np.uint8)[rng.integers(0, 11, hl)]
+        h[100:130] = ord("0")
+        h[200:215] = ord("N")
+    reads, quals, pos, ph, pr = [], [], [], [], []
+    for h, hp in enumerate(haps):
+        for _ in range(per):
+            o = int(rng.integers(0, hl - rl - 20))
+            s = hp[o:o + rl].copy()
+            sub = rng.random(rl) < 0.05
+            s[sub] = alphabet[rng.integers(0, len(alphabet), int(sub.sum()))]
+            if rng.random() < 0.3:
+                s = np.concatenate([s[:40], s[43:]])
+            reads.append(s); quals.append(rng.integers(0, 94, len(s)).astype(np.uint8)); pos.append(1000 + o)
+            ph.append(h); pr.append(len(reads) - 1)
+    b = dict(hap_seq=np.concatenate(haps), hap_off=(np.arange(n_h + 1) * hl).astype(np.int64),
+             hap_start=np.full(n_h, 1000, np.int32), hap_varlen=np.array([0, 2] * (n_h // 2), np.int32),
+             read_seq=np.concatenate(reads), read_qual=np.concatenate(quals),
+             read_off=np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.int64),
+             read_pos=np.array(pos, np.int32), read_mapq=np.full(len(reads), 50, np.int32),
+             pair_hap=np.array(ph, np.int32), pair_read=np.array(pr, np.int32))
+    _check_batch(ctx, b)
+    for bad in (0, 32, 127, 200, 255):
+        hs = b["hap_seq"].copy(); hs[7] = bad
+        with pytest.raises(native.PlatGpuError) as e:
+            ctx.upload_haps(hs, b["hap_off"], b["hap_start"], b["hap_varlen"])
+        assert e.value.code == native.PG_ERR_UNSUPPORTED
+        rs = b["read_seq"].copy(); rs[11] = bad
+        with pytest.raises(native.PlatGpuError) as e:
+            ctx.upload_reads(rs, b["read_qual"], b["read_off"], b["read_pos"], b["read_mapq"])
+        assert e.value.code == native.PG_ERR_UNSUPPORTED
+    with pytest.raises(native.PlatGpuError) as e:                 # run lengths are kept in 7 bits
+        ctx.set_params(3, 2, bytes([40] * 129))
+    assert e.value.code == native.PG_ERR_INVALID
+    ctx.set_params(3, 2, bytes([97 - i // 2 for i in range(128)]))  # the longest table taken
+    try:
+        b2 = dict(b); b2["hap_seq"] = b["hap_seq"].copy(); b2["hap_seq"][500:700] = ord("A")   # runs up to 127
+        from oracle import pyoracle as po
+        from platypus_amd import synth
+        exp = po.run_pairs(synth.oracle_view(b2), threads=8, reuse_hash=True, gapextend=3, nucprior=2,
+                           table=bytes([97 - i // 2 for i in range(128)]))
+        _check_batch(ctx, b2, *exp)
+    finally:
+        ctx.set_params()
+
+
 def test_genotype_loglik(ctx):
     from oracle import pyoracle as po
     from platypus_amd import synth
