@@ -339,12 +339,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     vote_fetch(Q, read2 + rec.r2off, part, votes_of(rec), (votes_of(rec) + 15) >> 4);
     vote_fetch(Q_next, read2 + rec_next.r2off, part, votes_of(rec_next), (votes_of(rec_next) + 15) >> 4);
 
-    {   // the table starts empty (platypus/calign.pyx:105; "no start" is 0xffff here, as is "repeated"), counters at zero
-        const int tab_dw = kHashSize / 2, total_dw = (kHashSize + n_wav * cnt_stride) / 2;
+    {   // the table starts empty (platypus/calign.pyx:105; "no start" is 0xffff here, as is "repeated")
         uint4* z = reinterpret_cast<uint4*>(lds);
-        for (int i = tid; i < (tab_dw >> 2); i += n_thr) z[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
-        for (int i = tab_dw + tid; i < total_dw; i += n_thr) lds[i] = 0;
+        for (int i = tid; i < (kHashSize / 8); i += n_thr) z[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
     }
+    bool counters_ready = false;        // a wavefront's vote counters are zeroed when it first needs them
     __syncthreads();
 #pragma unroll
     for (int m = 0; m < 4; ++m) { const int i = tid + m * n_thr; if (i < nk) tab[hk[m]] = (uint16_t)(i + 1); }
@@ -495,6 +494,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const int pair = __builtin_amdgcn_readlane(rec.pair, j);
             const int rlj = __builtin_amdgcn_readlane(rec.rlen, j);
             const int nvj = rlj - kHashNucs;
+            if (!counters_ready) {
+                for (int i = lane; i < cnt_stride / 2; i += 64) cnt32[i] = 0;      // cnt_stride is even
+                counters_ready = true;
+            }
             if (nvj <= 256) {
                 // the read's words are in the registers of its four lanes
                 if ((lane >> 2) == (j >> 2)) {
