@@ -29,24 +29,34 @@ def _stale(mod):
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+# test-only module that cimports the layer the way the reference's callers do (tests/cy_dropin/refcalls.pyx)
+TEST_MODULES = [(os.path.join(ROOT, "tests", "cy_dropin"), "refcalls")]
+
+
 def build(force=False, verbose=True):
     from Cython.Build import cythonize  # noqa: F401  (fails early if Cython is missing)
     import numpy as np
     inc = [sysconfig.get_paths()["include"], np.get_include(), os.path.join(ROOT, "include")]
     build_dir = os.path.join(HERE, "_cybuild")
     os.makedirs(build_dir, exist_ok=True)
-    for mod in MODULES:
-        if not force and not _stale(mod):
+    for src_dir, mod in [(HERE, m) for m in MODULES] + TEST_MODULES:
+        out = os.path.join(src_dir, mod + sysconfig.get_config_var("EXT_SUFFIX"))
+        if src_dir == HERE:
+            stale = _stale(mod)
+        else:       # after the layer's modules: rebuilt whenever one of them or its own source is newer
+            deps = [os.path.join(src_dir, mod + ".pyx")] + [os.path.join(HERE, p) for p in PXD]
+            stale = not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps)
+        if not force and not stale:
             continue
         c_file = os.path.join(build_dir, mod + ".c")
-        cmd = [sys.executable, "-m", "cython", "-3", "-I", ROOT, "-o", c_file, os.path.join(HERE, mod + ".pyx")]
+        cmd = [sys.executable, "-m", "cython", "-3", "-I", ROOT, "-o", c_file, os.path.join(src_dir, mod + ".pyx")]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd, cwd=ROOT)
         cc = ["gcc", "-O3", "-fPIC", "-shared", "-fno-strict-aliasing", "-Wno-unused-function",
               "-DNPY_NO_DEPRECATED_API=NPY_1_7_API_VERSION"] + ["-I" + i for i in inc] + \
-             ["-o", _ext_path(mod), c_file, "-L" + os.path.join(HERE, "lib"), "-lplatgpu",
-              "-Wl,-rpath,$ORIGIN/lib", "-lm"] + (["-lz", "-ldl"] if mod == "cbam" else [])
+             ["-o", out, c_file, "-L" + os.path.join(HERE, "lib"), "-lplatgpu",
+              "-Wl,-rpath," + ("$ORIGIN/lib" if src_dir == HERE else "$ORIGIN/../../platypus_amd/lib"), "-lm"] + (["-lz", "-ldl"] if mod == "cbam" else [])
         if verbose:
             print(" ".join(cc), flush=True)
         subprocess.check_call(cc)

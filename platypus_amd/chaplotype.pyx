@@ -5,8 +5,9 @@ Mirrors the part of platypus/chaplotype.pyx the alignment path uses: the
 fields alignNoTraceback is fed from (cHaplotypeSequence, startPos, hapLen,
 varSeqLen, cHomopolQ -- chaplotype.pyx:50-86), ``alignReads`` with its
 per-individual cache (chaplotype.pyx:239-270) and the cache's life time
-(chaplotype.pyx:88-100).  The mutated sequence is handed in ready-made: building
-it from variants (chaplotype.pyx:283-353) belongs to the caller.
+(chaplotype.pyx:88-100).  The constructor is the reference's: window, variants, reference file, read
+length (chaplotype.pyx:50-86, getMutatedSequence :283-353); ``Haplotype.fromSequence`` takes a
+ready-made sequence instead.
 
 ``prefetchWindow`` is the batch hook: called once at the top of Caller.setup
 (cpopulation.pyx:658), it scores every haplotype of the window against every
@@ -31,11 +32,71 @@ cdef bytes homopolq = bytes([int(33.5 + 10 * math.log((idx + 1) * q) / math.log(
                              for idx, q in enumerate(per_base_indel_errors)])
 
 
+cdef bytes mutatedSequence(bytes refName, int startPos, int endPos, tuple variants, refFile):
+    """getMutatedSequence, chaplotype.pyx:283-353, over the padded bounds [startPos, endPos)"""
+    cdef int currentPos
+    if len(variants) == 0:
+        return refFile.getSequence(refName, startPos, endPos)
+    currentPos = startPos
+    bits = [refFile.getSequence(refName, currentPos, variants[0].refPos)]
+    currentPos = variants[0].refPos
+    for v in variants:
+        if v.refPos > currentPos:                      # up to the next variant
+            bits.append(refFile.getSequence(refName, currentPos, v.refPos))
+            currentPos = v.refPos
+        if v.nAdded == v.nRemoved:                     # SNP / multi-nucleotide substitution
+            bits.append(v.added)
+            currentPos += v.nAdded
+        elif v.nAdded == 0 and v.nRemoved > 0:         # deletion: position = base before it
+            if v.refPos == currentPos:
+                bits.append(refFile.getCharacter(refName, v.refPos))
+                currentPos += 1
+            currentPos += v.nRemoved
+        elif v.nAdded > 0 and v.nRemoved == 0:         # insertion after the base at refPos
+            if v.refPos == currentPos:
+                bits.append(refFile.getCharacter(refName, v.refPos))
+                currentPos += 1
+            bits.append(v.added)
+        else:
+            raise ValueError("Variant type %s not yet supported in getMutatedSequence()" % (v,))
+    if currentPos < endPos:
+        bits.append(refFile.getSequence(refName, currentPos, endPos))
+    return b"".join(bits)
+
+
+cpdef bint variantsCompatible(tuple variants) except -1:
+    """The rule of Haplotype.valid (chaplotype.pyx:189-237): the sorted variants must not overlap; an
+    insertion may touch what follows.  Usable before the haplotype's sequence is built."""
+    cdef int index, nVariants = len(variants)
+    for index in range(nVariants - 1):
+        thisVar = variants[index]
+        nextVar = variants[index + 1]
+        if thisVar.minPos > nextVar.minPos:
+            raise ValueError("Variants out of order in haplotype!")                    # chaplotype.pyx:222-224
+        if thisVar.maxPos >= nextVar.minPos:
+            if (thisVar.nAdded > 0 and thisVar.nRemoved == 0) and (nextVar.nAdded == 0 and nextVar.nRemoved == 0):
+                continue
+            return False
+    return True
+
+
 cdef class Haplotype:
-    def __init__(self, bytes refName, int startPos, int endPos, bytes haplotypeSequence,
-                 int varSeqLen, tuple variants=()):
-        """startPos/endPos are the padded bounds of chaplotype.pyx:70-71, varSeqLen the
-        sum of |nAdded - nRemoved| over the variants (chaplotype.pyx:66-68)."""
+    def __init__(self, bytes refName, int startPos, int endPos, tuple variants, refFile, int maxReadLength):
+        """The reference's constructor (chaplotype.pyx:50-86): pad the window by twice the read
+        length, clamp to the sequence, and apply the (sorted) variants to the reference
+        (getMutatedSequence, chaplotype.pyx:283-353).  `refFile` offers getSequence,
+        getCharacter and refs[name].SeqLength (platypus_amd.fastafile.FastaFile)."""
+        cdef int varSeqLen = 0
+        for v in variants:
+            varSeqLen += abs(v.nAdded - v.nRemoved)                              # chaplotype.pyx:66-67
+        startPos = max(0, startPos - 2 * maxReadLength)                          # chaplotype.pyx:70-71
+        endPos = min(endPos + 2 * maxReadLength, refFile.refs[refName].SeqLength)
+        self.refFile = refFile
+        self.setUp(refName, startPos, endPos, mutatedSequence(refName, startPos, endPos, variants, refFile),
+                   varSeqLen, variants)
+
+    cdef void setUp(self, bytes refName, int startPos, int endPos, bytes haplotypeSequence, int varSeqLen,
+                    tuple variants):
         self.refName = refName
         self.startPos = startPos
         self.endPos = endPos
@@ -50,45 +111,18 @@ cdef class Haplotype:
         self.lenCache = 0
 
     @staticmethod
-    def fromVariants(bytes refName, int startPos, int endPos, tuple variants, refFile, int maxReadLength):
-        """The reference's constructor (chaplotype.pyx:50-86): pad the window by twice the read
-        length, clamp to the sequence, and apply the (sorted) variants to the reference
-        (getMutatedSequence, chaplotype.pyx:283-353).  `refFile` offers getSequence,
-        getCharacter and refs[name].SeqLength (platypus_amd.fastafile.FastaFile)."""
-        cdef int varSeqLen = 0, currentPos
-        for v in variants:
-            varSeqLen += abs(v.nAdded - v.nRemoved)                              # chaplotype.pyx:66-67
-        startPos = max(0, startPos - 2 * maxReadLength)                          # chaplotype.pyx:70-71
-        endPos = min(endPos + 2 * maxReadLength, refFile.refs[refName].SeqLength)
-        if len(variants) == 0:
-            seq = refFile.getSequence(refName, startPos, endPos)
-        else:
-            currentPos = startPos
-            bits = [refFile.getSequence(refName, currentPos, variants[0].refPos)]
-            currentPos = variants[0].refPos
-            for v in variants:
-                if v.refPos > currentPos:                      # up to the next variant
-                    bits.append(refFile.getSequence(refName, currentPos, v.refPos))
-                    currentPos = v.refPos
-                if v.nAdded == v.nRemoved:                     # SNP / multi-nucleotide substitution
-                    bits.append(v.added)
-                    currentPos += v.nAdded
-                elif v.nAdded == 0 and v.nRemoved > 0:         # deletion: position = base before it
-                    if v.refPos == currentPos:
-                        bits.append(refFile.getCharacter(refName, v.refPos))
-                        currentPos += 1
-                    currentPos += v.nRemoved
-                elif v.nAdded > 0 and v.nRemoved == 0:         # insertion after the base at refPos
-                    if v.refPos == currentPos:
-                        bits.append(refFile.getCharacter(refName, v.refPos))
-                        currentPos += 1
-                    bits.append(v.added)
-                else:
-                    raise ValueError("Variant type %s not yet supported in getMutatedSequence()" % (v,))
-            if currentPos < endPos:
-                bits.append(refFile.getSequence(refName, currentPos, endPos))
-            seq = b"".join(bits)
-        return Haplotype(refName, startPos, endPos, seq, varSeqLen, variants)
+    def fromSequence(bytes refName, int startPos, int endPos, bytes haplotypeSequence, int varSeqLen,
+                     tuple variants=()):
+        """A haplotype whose mutated sequence is known already.  startPos/endPos are the padded bounds of
+        chaplotype.pyx:70-71, varSeqLen the sum of |nAdded - nRemoved| over the variants (chaplotype.pyx:66-68)."""
+        cdef Haplotype h = Haplotype.__new__(Haplotype)
+        h.refFile = None
+        h.setUp(refName, startPos, endPos, haplotypeSequence, varSeqLen, variants)
+        return h
+
+    cpdef int valid(self) except -1:
+        """chaplotype.pyx:189-237"""
+        return variantsCompatible(self.variants)
 
     def __dealloc__(self):
         cdef int index

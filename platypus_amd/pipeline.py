@@ -66,7 +66,7 @@ def convertVariantToStandardFormat(variant, refFile, maxReadLength):
     windowMin = max(1, variant.refPos - window)
     windowMax = min(variant.refPos + window, seqMax)
     ref = refFile.getSequence(variant.refName, windowMin, windowMax)
-    hap = chaplotype.Haplotype.fromVariants(variant.refName, windowMin, windowMax, (variant,), refFile, 0).sequence
+    hap = chaplotype.Haplotype(variant.refName, windowMin, windowMax, (variant,), refFile, 0).sequence
     lenRef, lenHap = len(ref), len(hap)
     # the first mismatch from the right = the length of the longest common suffix; 'a suffix of
     # length k matches' is monotone in k, so it is found by bisection over slice comparisons
@@ -171,15 +171,8 @@ class WindowGenerator(object):
 
 # ---------------------------------------------------------------------------------------------
 def validHaplotype(variants):
-    """chaplotype.pyx:189-237: variants (sorted) must not overlap; an insertion may touch what follows."""
-    for this, nxt in zip(variants, variants[1:]):
-        if this.minPos > nxt.minPos:
-            raise ValueError("Variants out of order in haplotype!")
-        if this.maxPos >= nxt.minPos:
-            if (this.nAdded > 0 and this.nRemoved == 0) and (nxt.nAdded == 0 and nxt.nRemoved == 0):
-                continue
-            return False
-    return True
+    """chaplotype.pyx:189-237 (Haplotype.valid), asked before the sequence is built"""
+    return chaplotype.variantsCompatible(tuple(variants))
 
 
 def haplotypesInWindow(window, nReads, refFile, options):
@@ -187,7 +180,7 @@ def haplotypesInWindow(window, nReads, refFile, options):
     haplotype is added by the caller): every valid combination of the window's variants, if
     there are at most maxHaplotypes of them."""
     chrom, ws, we, variants = window["chromosome"], window["startPos"], window["endPos"], window["variants"]
-    make = lambda vs: chaplotype.Haplotype.fromVariants(chrom, ws, we, tuple(vs), refFile, options.rlen)
+    make = lambda vs: chaplotype.Haplotype(chrom, ws, we, tuple(vs), refFile, options.rlen)
     if nReads == 0:
         return []
     coverage = (nReads * options.rlen) / (we - ws + options.rlen)
@@ -369,12 +362,12 @@ def callRegion(chrom, start, end, readBuffers, refFile, options=None, variants=N
     pre_ids = []
     for i, w in enumerate(windows):
         prepare(i, w)
-        refHap[i] = chaplotype.Haplotype.fromVariants(chrom, w["startPos"], w["endPos"], (), refFile, options.rlen)
+        refHap[i] = chaplotype.Haplotype(chrom, w["startPos"], w["endPos"], (), refFile, options.rlen)
         vs = w["variants"]
         if len(vs) > options.maxVariants and nReads[i] > 0:
             if len(vs) > 50:                                          # variantcaller.pyx:146-149
                 vs = sorted(sorted(vs, key=lambda v: v.nSupportingReads, reverse=True)[:50])
-            haps = [refHap[i]] + [chaplotype.Haplotype.fromVariants(chrom, w["startPos"], w["endPos"], (v,), refFile,
+            haps = [refHap[i]] + [chaplotype.Haplotype(chrom, w["startPos"], w["endPos"], (v,), refFile,
                                                                       options.rlen) for v in vs]
             pre.add(haps, readBuffers, w["startPos"], w["endPos"])
             pre_ids.append((i, vs))
@@ -491,8 +484,8 @@ def callRegion(chrom, start, end, readBuffers, refFile, options=None, variants=N
             if len(vs) == 1:                                          # GL of AA/AB/BB: variantcaller.pyx:371-378,419-429
                 w = windows[i]
                 h0 = pop.haplotypes[0]
-                rh = chaplotype.Haplotype.fromVariants(chrom, h0.startPosPy, h0.endPosPy, (), refFile, 0)
-                vh = chaplotype.Haplotype.fromVariants(chrom, h0.startPosPy, h0.endPosPy, (vs[0],), refFile, 0)
+                rh = chaplotype.Haplotype(chrom, h0.startPosPy, h0.endPosPy, (), refFile, 0)
+                vh = chaplotype.Haplotype(chrom, h0.startPosPy, h0.endPosPy, (vs[0],), refFile, 0)
                 site_items.append((k, rh, vh))
                 site_calls.append(c)
             calls.append(c)

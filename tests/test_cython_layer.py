@@ -60,7 +60,7 @@ def test_haplotype_align_reads_prefetch_and_genotypes():
         haps = []
         for h in range(w * H, (w + 1) * H):
             seq = b["hap_seq"][b["hap_off"][h]:b["hap_off"][h + 1]].tobytes()
-            haps.append(chaplotype.Haplotype(b"chr20", int(b["hap_start"][h]), int(b["hap_start"][h]) + len(seq),
+            haps.append(chaplotype.Haplotype.fromSequence(b"chr20", int(b["hap_start"][h]), int(b["hap_start"][h]) + len(seq),
                                              seq, int(b["hap_varlen"][h])))
         buf.setWindow(int(b["hap_start"][w * H]) + 200, int(b["hap_start"][w * H]) + 320)
         lo, hi = buf.windowRange()
@@ -148,7 +148,7 @@ def test_caller_setup_call_and_variant_posterior():
         for k, h in enumerate(range(w * H, (w + 1) * H)):
             seq = b["hap_seq"][b["hap_off"][h]:b["hap_off"][h + 1]].tobytes()
             vs = () if k == 0 else ((variants[k],) if k != 2 else (variants[1], variants[2]))
-            haps.append(chaplotype.Haplotype(b"chr20", int(b["hap_start"][h]), int(b["hap_start"][h]) + len(seq),
+            haps.append(chaplotype.Haplotype.fromSequence(b"chr20", int(b["hap_start"][h]), int(b["hap_start"][h]) + len(seq),
                                              seq, int(b["hap_varlen"][h]), vs))
         reads = np.arange(w * R, (w + 1) * R)
         groups = [reads[0::3], reads[:0], reads[1::3], reads[2::3]]      # the second individual has no reads
@@ -205,7 +205,7 @@ def test_window_batch_equals_window_by_window():
         haps = []
         for k, h in enumerate(range(w * H, (w + 1) * H)):
             seq = b["hap_seq"][b["hap_off"][h]:b["hap_off"][h + 1]].tobytes()
-            haps.append(chaplotype.Haplotype(b"chr20", int(b["hap_start"][h]), int(b["hap_start"][h]) + len(seq),
+            haps.append(chaplotype.Haplotype.fromSequence(b"chr20", int(b["hap_start"][h]), int(b["hap_start"][h]) + len(seq),
                                              seq, int(b["hap_varlen"][h]), () if k == 0 else (variants[k],)))
         reads = np.arange(w * R, (w + 1) * R)
         bufs = [_buffer_of(b, reads[0::2])[1], _buffer_of(b, reads[1::2])[1]]
@@ -269,8 +269,8 @@ def test_site_likelihoods_second_alignment_site():
         var = [Variant(b"c", ws + 20, genome[ws + 20:ws + 21], b"A" if genome[ws + 20:ws + 21] != b"A" else b"C"),
                Variant(b"c", ws + 20, b"", b"GTG"),
                Variant(b"c", ws + 20, genome[ws + 21:ws + 23], b"")][w % 3]
-        refHap = chaplotype.Haplotype.fromVariants(b"c", ws, ws + 40, (), ref, L)
-        varHap = chaplotype.Haplotype.fromVariants(b"c", ws, ws + 40, (var,), ref, L)
+        refHap = chaplotype.Haplotype(b"c", ws, ws + 40, (), ref, L)
+        varHap = chaplotype.Haplotype(b"c", ws, ws + 40, (var,), ref, L)
         # reads sampled from either haplotype, two individuals (the second one empty in window 4)
         seqs, quals, poss = [], [], []
         for r in range(24):
@@ -343,4 +343,63 @@ def test_hash_sequence_and_map_read_cdefs():
         read = seq[o:o + 90]
         assert calign.mapReadPy(read, seq) == po.map_read(read, len(seq), want) == o
     assert calign.mapReadPy(b"ACG", seq) == 0
+    calign.closeDevice()
+
+
+def test_reference_call_sites_compile_against_the_layer():
+    """tests/cy_dropin/refcalls.pyx cimports platypus_amd's .pxd files unchanged and makes the calls of
+    cgenotype.pyx:55-56, variantcaller.pyx:130 and :373-374 with the reference's argument lists; it is built
+    with the layer (platypus_amd.build_cython), so importing it proves the interface still fits."""
+    from tests.cy_dropin import refcalls
+    for name in ("windowHaplotypes", "calculateDataLikelihood", "perReadLikelihoods", "anchors"):
+        assert callable(getattr(refcalls, name))
+
+
+@pytest.mark.gpu
+def test_reference_call_sites_against_checker():
+    """The same calls on the GPU: the reference's constructor form, alignReads through the genotype sum of
+    cgenotype.pyx:58-61, alignNoTraceback read by read, hash_sequence + map_read -- against the CPU checker."""
+    from oracle import pyoracle as po
+    from platypus_amd import calign, cwindow
+    from platypus_amd.fastafile import FastaFile
+    from platypus_amd.variant import Variant
+    from tests.cy_dropin import refcalls
+    rng = np.random.default_rng(191)
+    L, G = 80, 3000
+    genome = bytes(b"ACGT"[i] for i in rng.integers(0, 4, G))
+    ref = FastaFile(sequences={b"c": genome})
+    for case, var in enumerate([Variant(b"c", 1020, genome[1020:1021], b"A" if genome[1020:1021] != b"A" else b"C"),
+                                Variant(b"c", 1020, b"", b"GTGA"), Variant(b"c", 1020, genome[1021:1024], b"")]):
+        refHaplotype, testHap, refHap, varHap = refcalls.windowHaplotypes(b"c", 1000, 1040, var, ref, L)
+        # variantcaller.pyx:373-374 builds over the padded bounds with read length 0: same stretch, same sequence
+        assert (refHap.startPosPy, refHap.endPosPy) == (1000 - 2 * L, 1040 + 2 * L) == (testHap.startPosPy, testHap.endPosPy)
+        assert refHap.sequence == refHaplotype.sequence == genome[1000 - 2 * L:1040 + 2 * L]
+        assert varHap.sequence == testHap.sequence and varHap.varSeqLenPy == abs(var.nAdded - var.nRemoved)
+        seqs, quals, poss = [], [], []
+        for r in range(40):
+            src = (refHap, varHap)[r % 2].sequence
+            o = int(rng.integers(2 * L - 70, 2 * L - 5))
+            s = bytearray(src[o:o + L])
+            for j in np.flatnonzero(rng.random(L) < 0.02):
+                s[j] = b"ACGT"[int(rng.integers(0, 4))]
+            seqs.append(bytes(s)); quals.append(bytes(rng.integers(5, 41, L).astype(np.uint8))); poss.append(refHap.startPosPy + o)
+        order = np.argsort(poss, kind="stable")
+        seqs = [seqs[i] for i in order]; quals = [quals[i] for i in order]; poss = [poss[i] for i in order]
+        pos = np.array(poss, np.int32)
+        buf = cwindow.bamReadBuffer(b"c", int(pos.min()), int(pos.max()) + 100, np.frombuffer(b"".join(seqs), np.uint8),
+                                    np.frombuffer(b"".join(quals), np.uint8), np.arange(41, dtype=np.int64) * L, pos, pos + L,
+                                    np.full(40, 45, np.int32))
+        buf.setWindow(int(pos.min()), int(pos.max()) + 1)
+        rows = {}
+        for name, hp in (("ref", refHap), ("var", varHap)):
+            exp = [po.align_no_traceback(seqs[i], quals[i], poss[i], hp.sequence, hp.startPosPy, hp.varSeqLenPy)
+                   for i in range(40)]
+            rows[name] = np.array([po.likelihood(sc, 45) for sc, _ in exp])
+            assert refcalls.perReadLikelihoods(hp, buf) == list(rows[name])            # same doubles
+            tab = po.hash_sequence(hp.sequence)
+            assert refcalls.anchors(hp, buf) == [po.map_read(seqs[i], len(hp.sequence), tab) for i in range(40)]
+        for a, b in (("ref", "ref"), ("ref", "var"), ("var", "var")):
+            got = refcalls.calculateDataLikelihood({"ref": refHap, "var": varHap}[a], {"ref": refHap, "var": varHap}[b], buf, 0, 1)
+            want = po.genotype_loglik(rows[a], rows[b])
+            assert abs(got - want) <= 1e-9 * abs(want)
     calign.closeDevice()

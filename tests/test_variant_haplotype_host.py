@@ -72,23 +72,23 @@ def test_haplotype_from_variants():
     from platypus_amd import chaplotype
     ref = FastaFile(sequences={b"c": REF})
     # padding by 2 * maxReadLength, clamped to the sequence (chaplotype.pyx:70-71)
-    h = chaplotype.Haplotype.fromVariants(b"c", 20, 30, (), ref, 4)
+    h = chaplotype.Haplotype(b"c", 20, 30, (), ref, 4)
     assert (h.startPosPy, h.endPosPy) == (12, 38) and h.sequence == REF[12:38] and h.varSeqLenPy == 0
-    h = chaplotype.Haplotype.fromVariants(b"c", 3, 45, (), ref, 4)
+    h = chaplotype.Haplotype(b"c", 3, 45, (), ref, 4)
     assert (h.startPosPy, h.endPosPy) == (0, 50) and h.sequence == REF[:49]   # getSequence cannot return the last base
     snp = Variant(b"c", 10, b"G", b"T")
     ins = Variant(b"c", 15, b"", b"GG")                 # after the base at 15
     dele = Variant(b"c", 24, b"CC", b"")                # bases 25 and 26 go, 24 stays
-    h = chaplotype.Haplotype.fromVariants(b"c", 8, 30, (snp, ins, dele), ref, 1)
+    h = chaplotype.Haplotype(b"c", 8, 30, (snp, ins, dele), ref, 1)
     want = REF[6:10] + b"T" + REF[11:16] + b"GG" + REF[16:25] + REF[27:32]
     assert h.sequence == want and h.varSeqLenPy == 4 and h.variantsPy() == (snp, ins, dele)
     # a SNP and an insertion at the same position: the SNP replaces the base, the insertion follows it
     snp15 = Variant(b"c", 15, b"T", b"A")
-    h = chaplotype.Haplotype.fromVariants(b"c", 8, 30, (snp15, ins), ref, 1)
+    h = chaplotype.Haplotype(b"c", 8, 30, (snp15, ins), ref, 1)
     assert h.sequence == REF[6:15] + b"A" + b"GG" + REF[16:32]
     # a multi-nucleotide substitution
     mnp = Variant(b"c", 20, b"AAA", b"CGC")
-    h = chaplotype.Haplotype.fromVariants(b"c", 18, 26, (mnp,), ref, 0)
+    h = chaplotype.Haplotype(b"c", 18, 26, (mnp,), ref, 0)
     assert h.sequence == REF[18:20] + b"CGC" + REF[23:26]
     with pytest.raises(ValueError):
-        chaplotype.Haplotype.fromVariants(b"c", 8, 30, (Variant(b"c", 12, b"AC", b"G"),), ref, 1)
+        chaplotype.Haplotype(b"c", 8, 30, (Variant(b"c", 12, b"AC", b"G"),), ref, 1)
