@@ -37,4 +37,5 @@ cdef int alignBatch(
 ) except -1
 
 cdef pg_ctx* deviceContext() except NULL
+cdef int ensureReadLength(int n) except -1
 cdef int setParams(char* table, int gapextend, int nucprior) except -1

@@ -35,14 +35,35 @@ cdef int check(int rc) except -1:
     return 0
 
 
+cdef int g_max_read_len = 0          # read length the context was (or will be) created for; 0: not decided yet
+
+
+cdef int ensureReadLength(int n) except -1:
+    """Make sure the device context takes reads of n bases: a context made for shorter reads is
+    replaced (device haplotypes carry that many trailing 'N's, so the limit is fixed at creation).
+    Results of earlier launches are gone after a replacement."""
+    global g_max_read_len
+    if n > 16384:
+        raise ValueError("a read of %d bases: the device path takes at most 16384" % n)
+    if g_max_read_len == 0:
+        g_max_read_len = max(512, int(os.environ.get("PLATGPU_MAX_READ_LEN", "0")))
+    if n > g_max_read_len:
+        closeDevice()
+        while g_max_read_len < n:
+            g_max_read_len *= 2
+        g_max_read_len = min(g_max_read_len, 16384)
+    return 0
+
+
 cdef pg_ctx* deviceContext() except NULL:
     """One device context per process (the unit runner.py:132 spreads over workers).
-    PLATGPU_DEVICE selects the GPU, PLATGPU_MAX_READ_LEN the longest read accepted."""
+    PLATGPU_DEVICE selects the GPU; the longest read accepted starts at 512 (or PLATGPU_MAX_READ_LEN)
+    and grows with ensureReadLength."""
     global g_ctx
     cdef int rc
     if g_ctx == NULL:
-        rc = pg_ctx_create(int(os.environ.get("PLATGPU_DEVICE", "0")),
-                           int(os.environ.get("PLATGPU_MAX_READ_LEN", "0")), &g_ctx)
+        ensureReadLength(1)
+        rc = pg_ctx_create(int(os.environ.get("PLATGPU_DEVICE", "0")), g_max_read_len, &g_ctx)
         if rc != PG_OK:
             msg = pg_last_error_string(NULL)
             g_ctx = NULL
@@ -73,6 +94,11 @@ cdef int alignBatch(int nHaps, char** hapSeqs, int* hapStarts, int* varSeqLens, 
     cdef int64_t tot = 0
     if nHaps <= 0 or nReads <= 0:
         return 0
+    cdef int longest = 1
+    for r in range(nReads):
+        if start[r].rlen > longest:
+            longest = start[r].rlen
+    ensureReadLength(longest)
     setParams(homopolgapq, gapextend, nucprior)
     # haplotypes, concatenated
     cdef int64_t* hoff = <int64_t*>malloc((nHaps + 1) * sizeof(int64_t))

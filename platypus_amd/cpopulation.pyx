@@ -19,7 +19,7 @@ from libc.string cimport memcpy, memset
 from libc.math cimport exp
 import time
 
-from platypus_amd.calign cimport deviceContext
+from platypus_amd.calign cimport deviceContext, ensureReadLength
 from platypus_amd.calign import PlatGpuError
 from platypus_amd.chaplotype cimport Haplotype, prefetchWindowC
 from platypus_amd.cgenotype cimport DiploidGenotype, generateAllGenotypesFromHaplotypeList
@@ -271,10 +271,22 @@ cdef class WindowBatch:
         cdef int i, n, tot = 0
         cdef list counts = []
         cdef list firsts = []
+        cdef Haplotype hap
         if len(haplotypes) < 1 or len(haplotypes) > 1000:
             raise ValueError("a window needs 1..1000 haplotypes (cpopulation.pyx:546)")
+        for hp in haplotypes:
+            # what the device refuses, found here so that only this window is lost (the reference skips a window
+            # that fails, variantcaller.pyx:189-191): the 7-mer table of calign.pyx:112,132 ends at 16383 bases,
+            # and below 15 the reference reads past its own 'N' extension (calign.pyx:73-77)
+            hap = hp
+            if hap.varSeqLen != 0 and (hap.hapLen < 15 or hap.hapLen > 16383):
+                raise ValueError("a haplotype with indels of %d bases (15..16383 are taken)" % hap.hapLen)
+        if len(readBuffers) > 4096:
+            raise ValueError("more than 4096 read buffers in one window")
         for i in range(len(readBuffers)):
             buf = readBuffers[i]
+            if buf.maxReadLen > 16384:
+                raise ValueError("a read of %d bases (at most 16384 are taken)" % buf.maxReadLen)
             if start is not None:
                 buf.setWindowPointers(start, end)
             n = <int>(buf.windowEnd - buf.windowStart)
@@ -347,8 +359,12 @@ cdef class WindowBatch:
         """One alignment launch and one genotype/EM launch for all windows added so far; returns their Populations.
         keepPosteriors=False leaves the genotype posteriors on the device (variant posteriors and genotype calls
         are computed there anyway): a caller that only needs calls saves the largest transfer of the batch."""
+        cdef int nW = len(self.windows), w, h, i, r, n, lo, cnt, longest = 1
+        for w in range(nW):
+            for b in self.windows[w][1]:
+                longest = max(longest, (<bamReadBuffer>b).maxReadLen)
+        ensureReadLength(longest)                         # may replace the context: before anything is uploaded
         cdef pg_ctx* ctx = deviceContext()
-        cdef int nW = len(self.windows), w, h, i, r, n, lo, cnt
         cdef int64_t nHapTot = 0, nReadTot = 0, nIndTot = 0, hapBytes = 0, readBytes = 0, nCells = 0
         cdef Haplotype hap
         cdef cAlignedRead* rd

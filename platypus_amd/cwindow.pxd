@@ -8,6 +8,7 @@ cdef class bamReadBuffer:
     cdef bytes chromBytes
     cdef char* chrom
     cdef int startBase, endBase, nReads, longestRead
+    cdef int maxReadLen                             # longest sequence among the buffered reads
     cdef cAlignedRead** cReads                      # all buffered reads, sorted by position
     cdef cAlignedRead** start                       # == cReads
     cdef cAlignedRead** end                         # one past the last read

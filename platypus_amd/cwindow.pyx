@@ -82,25 +82,35 @@ cdef class bamReadBuffer:
         self.chrom = self.chromBytes
         self.startBase = start
         self.endBase = end
-        self.nReads = n
+        self.nReads = 0                               # counts the records stored so far: what __dealloc__ frees
         self.longestRead = 0
-        self.cReads = <cAlignedRead**>malloc((n + 1) * sizeof(cAlignedRead*))
+        self.maxReadLen = 0
+        self.cReads = <cAlignedRead**>calloc(n + 1, sizeof(cAlignedRead*))
+        if self.cReads == NULL:
+            raise MemoryError()
         for i in range(n):
             rl = <int>(o[i + 1] - o[i])
+            if i > 0 and p[i] < p[i - 1]:
+                raise ValueError("reads are not sorted by position")
             r = <cAlignedRead*>calloc(1, sizeof(cAlignedRead))
+            if r == NULL:
+                raise MemoryError()
             r.seq = <char*>calloc(rl + 1, 1)
             r.qual = <char*>calloc(rl + 1, 1)
+            self.cReads[i] = r                        # from here on the record is freed with the buffer
+            self.nReads = i + 1
+            if r.seq == NULL or r.qual == NULL:
+                raise MemoryError()
             memcpy(r.seq, &s[o[i]], rl)
             memcpy(r.qual, &q[o[i]], rl)
             r.pos = p[i]
             r.rlen = rl
             r.end = e[i]
             r.mapq = m[i]
-            if i > 0 and p[i] < p[i - 1]:
-                raise ValueError("reads are not sorted by position")
             if r.end - r.pos > self.longestRead:      # cwindow.pyx:220-221
                 self.longestRead = r.end - r.pos
-            self.cReads[i] = r
+            if rl > self.maxReadLen:
+                self.maxReadLen = rl
         self.start = self.cReads
         self.end = self.cReads + n
         self.windowStart = self.cReads
@@ -153,7 +163,7 @@ cdef class bamReadBuffer:
         cdef char* bytesAt = self.slabBytes
         cdef int* intsAt = self.slabInts
         cdef cAlignedRead* recs = self.slabReads
-        cdef int longest = 0
+        cdef int longest = 0, maxlen = 0
         with nogil:                                                  # a helper thread can build the next buffer meanwhile
             for i in range(n):
                 if m[i] < minMapQual:                                   # cwindow.pyx:188-190
@@ -205,6 +215,8 @@ cdef class bamReadBuffer:
                     break
                 if r.end - r.pos > longest:
                     longest = r.end - r.pos
+                if rl > maxlen:
+                    maxlen = rl
                 reads[count] = r
                 count += 1
                 bytesAt += 2 * (rl + 1)
@@ -212,6 +224,7 @@ cdef class bamReadBuffer:
                 if count > maxReads:                                     # cwindow.pyx:221-223
                     break
         self.longestRead = longest
+        self.maxReadLen = maxlen
         if unsorted:
             self.nReads = count
             raise ValueError("records are not sorted by position")

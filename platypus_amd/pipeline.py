@@ -14,13 +14,17 @@ follow the reference's rules:
 File formats (BAM, VCF text) are not handled here: reads come in `bamReadBuffer`s, calls go
 out as Python records.
 """
+import bisect
 import functools
+import logging
 import math
 import time
 from itertools import combinations
 
 from platypus_amd import chaplotype, cpopulation, cwindow
 from platypus_amd.variant import Variant, VariantCandidateGenerator
+
+logger = logging.getLogger("Log")          # the reference's logger name (runner.py:61)
 
 
 class Options(object):
@@ -103,10 +107,13 @@ def convertVariantToStandardFormat(variant, refFile, maxReadLength):
     return newVar
 
 
-def filterVariants(varList, refFile, maxReadLength, minSupport, strandFilter, maxDiff):
+def filterVariants(varList, refFile, maxReadLength, minSupport, strandFilter, maxDiff, separators=()):
     """variantFilter.pyx:12-83: standard form, neighbours that became equal merged, support /
-    size / strand cuts, sorted."""
-    kept, last = [], None
+    size / strand cuts, sorted.  `separators` holds the ascending positions of single-base candidates
+    that were left out of varList because their support is below minSupport: the reference merges
+    neighbours of the full sorted list only (variantFilter.pyx:44), so two equal standard forms with
+    such an entry between them stay apart and are judged on their own support each."""
+    kept, last, prevPos = [], None, None
 
     def passes(v):
         if v.nSupportingReads < minSupport:
@@ -122,12 +129,14 @@ def filterVariants(varList, refFile, maxReadLength, minSupport, strandFilter, ma
         new = v if v.nAdded == v.nRemoved else convertVariantToStandardFormat(v, refFile, maxReadLength)
         if last is None:
             last = new
-        elif new == last:
+        elif new == last and not (separators and
+                                  bisect.bisect_right(separators, v.refPos) > bisect.bisect_right(separators, prevPos)):
             last.addVariant(new)
         else:
             if passes(last):
                 kept.append(last)
             last = new
+        prevPos = v.refPos
     if last is not None and passes(last):
         kept.append(last)
     return sorted(kept)
@@ -331,8 +340,10 @@ def candidatesInRegion(chrom, start, end, readBuffers, refFile, options):
                                     options.minBaseQual, options.genSNPs, options.genIndels)
     for buf in readBuffers:
         gen.addCandidatesFromBuffer(buf)
-    return filterVariants(gen.getCandidates(options.minReads), refFile, options.rlen, options.minReads, options.strandFilter,
-                          options.maxSize)
+    raw = gen.getCandidates(options.minReads)
+    kept = filterVariants(raw, refFile, options.rlen, options.minReads, options.strandFilter, options.maxSize,
+                          separators=gen.droppedSnpPositions)
+    return sorted(dict.fromkeys(kept))           # variantSet.update(...); sorted(variantSet): variantcaller.pyx:101,108
 
 
 def callRegion(chrom, start, end, readBuffers, refFile, options=None, variants=None, stats=None):
@@ -369,7 +380,12 @@ def callRegion(chrom, start, end, readBuffers, refFile, options=None, variants=N
                 vs = sorted(sorted(vs, key=lambda v: v.nSupportingReads, reverse=True)[:50])
             haps = [refHap[i]] + [chaplotype.Haplotype(chrom, w["startPos"], w["endPos"], (v,), refFile,
                                                                       options.rlen) for v in vs]
-            pre.add(haps, readBuffers, w["startPos"], w["endPos"])
+            try:
+                pre.add(haps, readBuffers, w["startPos"], w["endPos"])
+            except ValueError as e:                                   # only this window is lost, variantcaller.pyx:189-191
+                logger.warning("Window %s:%d-%d is skipped: %s", chrom.decode(), w["startPos"], w["endPos"], e)
+                nReads[i] = 0
+                continue
             pre_ids.append((i, vs))
     if len(pre):
         pre.run(options.maxIters, keepPosteriors=False)
@@ -398,7 +414,11 @@ def callRegion(chrom, start, end, readBuffers, refFile, options=None, variants=N
                 haps.append(h)
         if len(haps) <= 1:                                            # variantcaller.pyx:180-182
             continue
-        batch.add(haps, readBuffers, w["startPos"], w["endPos"])
+        try:
+            batch.add(haps, readBuffers, w["startPos"], w["endPos"])
+        except ValueError as e:                                       # only this window is lost, variantcaller.pyx:189-191
+            logger.warning("Window %s:%d-%d is skipped: %s", chrom.decode(), w["startPos"], w["endPos"], e)
+            continue
         order.append(i)
     if stats is not None:
         stats.update(windows=len(windows), called_windows=len(order), candidates=len(variants))

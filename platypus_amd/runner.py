@@ -12,6 +12,7 @@ nothing is exchanged between them.  Inside a chunk reads are buffered --bufferSi
 import argparse
 import collections
 import multiprocessing
+import logging
 import os
 import sys
 import tempfile
@@ -123,7 +124,11 @@ def call_chunks(chunks, args, tmpdir):
                     print(v)
                 continue
             t0 = time.perf_counter()
-            calls = pipeline.callRegion(chrom.encode(), s, e, bufs, fa, opts, variants=cands)
+            try:
+                calls = pipeline.callRegion(chrom.encode(), s, e, bufs, fa, opts, variants=cands)
+            except Exception as err:                          # one stretch is lost, the run goes on (variantcaller.pyx:189-191)
+                logging.getLogger("Log").error("No calls for %s:%d-%d: %s: %s", chrom, s, e, type(err).__name__, err)
+                calls = []
             t1 = time.perf_counter()
             for c in calls:
                 out.write(vcfout.record(c, fa) + "\n")

@@ -121,6 +121,7 @@ cdef class VariantCandidateGenerator:
     minFlank bases, and mismatching bases of quality >= minBaseQual inside matches of at least
     minFlank bases; equal candidates are merged and their support counted."""
     cdef dict variantHeap
+    cdef public list droppedSnpPositions     # see getCandidates
     cdef object refFile
     cdef bytes rname
     cdef bytes pyRefSeq
@@ -138,6 +139,9 @@ cdef class VariantCandidateGenerator:
 
     def __dealloc__(self):
         free(self.snpIndex); free(self.snpSums)
+
+    def __cinit__(self):
+        self.droppedSnpPositions = []
 
     def __init__(self, tuple region, refFile, int minMapQual=20, int minFlank=3, int minBaseQual=20,
                  int genSNPs=1, int genIndels=1):
@@ -330,9 +334,11 @@ cdef class VariantCandidateGenerator:
         free(todo)
 
     def getCandidates(self, int minSnpSupport=0):
-        """all candidates, sorted.  minSnpSupport > 0 leaves out single-base mismatches seen in fewer reads:
-        the filter that follows (variantFilter.pyx:12-83) drops them by the same count, and no other
-        candidate can merge with them, so the filtered list is the same and far shorter to sort"""
+        """all candidates, sorted.  minSnpSupport > 0 leaves out single-base mismatches seen in fewer reads
+        (the filter that follows, variantFilter.pyx:12-83, drops them by the same count) and records their
+        positions in self.droppedSnpPositions (ascending): the filter merges NEIGHBOURS of the sorted list
+        only, so a dropped entry still separates the two it stood between."""
+        cdef list dropped = []
         cdef size_t slot
         cdef Variant v
         cdef int k
@@ -342,6 +348,7 @@ cdef class VariantCandidateGenerator:
             slot = <size_t>acc.slot
             self.snpIndex[slot] = 0                        # handed over: a second call does not count them twice
             if acc.n < minSnpSupport:
+                dropped.append(<int>(slot >> 2) + self.refSeqStart)
                 continue
             v = Variant(self.rname, <int>(slot >> 2) + self.refSeqStart, bytes([self.refSeq[slot >> 2]]),
                         b"ACGT"[slot & 3:(slot & 3) + 1], acc.n, acc.fwd, 0, 0, 0)
@@ -351,4 +358,6 @@ cdef class VariantCandidateGenerator:
             v.nRevReadsWeighted = acc.revW
             self.addVariantToList(v)
         self.nSnpSums = 0
+        dropped.sort()
+        self.droppedSnpPositions = dropped
         return sorted(self.variantHeap.values())

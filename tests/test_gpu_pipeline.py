@@ -220,3 +220,48 @@ def test_print_candidates_and_exit(tmp_path, capsys):
     printed = [l for l in capsys.readouterr().out.splitlines() if l.strip()]
     assert len(truth) - 1 <= len(printed) <= len(truth)
     assert not [l for l in open(out).read().splitlines() if l and not l.startswith("#")]
+
+
+def test_windows_the_device_cannot_take_cost_only_themselves(caplog):
+    """A read longer than the context was made for makes the context grow; a window whose indel-bearing
+    haplotypes exceed the 7-mer table's 16383 bases (calign.pyx:112) is skipped with a warning, as the
+    reference skips a window that fails (variantcaller.pyx:189-191); the region's other windows are called."""
+    import logging
+    from platypus_amd import calign, pipeline, simulate
+    from platypus_amd.fastafile import FastaFile
+    rng = np.random.default_rng(23)
+    G = 40000
+    genome = simulate.random_genome(rng, G)
+    truth = simulate.plant_variants(rng, genome, 60, spacing=420, indel_frac=0.4)
+    reads = simulate.simulate_reads(rng, genome, truth, coverage=30, read_len=100, error_rate=0.003)
+    # one 600-base read (error-free copy of the reference, one CIGAR operation) in the middle of the region
+    at = int(np.searchsorted(reads["pos"], 20000))
+    p600 = int(reads["pos"][at])
+    seq600 = np.frombuffer(genome[p600:p600 + 600], np.uint8)
+    so, co = int(reads["off"][at]), int(reads["cigarOff"][at])
+    reads["seq"] = np.concatenate([reads["seq"][:so], seq600, reads["seq"][so:]])
+    reads["qual"] = np.concatenate([reads["qual"][:so], np.full(600, 35, np.uint8), reads["qual"][so:]])
+    reads["off"] = np.concatenate([reads["off"][:at + 1], reads["off"][at:] + 600]).astype(np.int64)
+    reads["cigar"] = np.concatenate([reads["cigar"][:co], np.array([600 << 4], np.uint32), reads["cigar"][co:]])
+    reads["cigarOff"] = np.concatenate([reads["cigarOff"][:at + 1], reads["cigarOff"][at:] + 1]).astype(np.int64)
+    for k, val in (("pos", p600), ("mapq", 60), ("flag", 0)):
+        reads[k] = np.concatenate([reads[k][:at], np.array([val], reads[k].dtype), reads[k][at:]])
+    fa = FastaFile(sequences={b"sim": genome})
+    calign.closeDevice()                                     # a fresh context: made for 512-base reads
+    buf = simulate.buffer_of(reads, 0, G)
+    calls = pipeline.callRegion(b"sim", 0, G, [buf], fa, pipeline.Options(rlen=100))
+    called = {(v.refPos, v.removed, v.added) for c in calls for v in c.variants}
+    assert sum((t[0], t[1], t[2]) in called for t in truth) >= len(truth) - 1
+    # --maxReadLength 4200: every haplotype is padded by 8400 bases on either side, so the indel-bearing ones
+    # are beyond the table's reach and their windows are skipped; windows of substitutions are still called
+    with caplog.at_level(logging.WARNING, logger="Log"):
+        calls = pipeline.callRegion(b"sim", 0, G, [buf], fa, pipeline.Options(rlen=4200))
+    called = {(v.refPos, v.removed, v.added) for c in calls for v in c.variants}
+    snps = [t for t in truth if len(t[1]) == len(t[2])]
+    # (near the ends of the sequence the padding is clipped, chaplotype.pyx:70-71, and the haplotypes fit)
+    indels = [t for t in truth if len(t[1]) != len(t[2]) and 8500 < t[0] < G - 8500]
+    assert len(snps) > 3 and len(indels) > 3
+    assert sum((t[0], t[1], t[2]) in called for t in snps) >= len(snps) - 1
+    assert not any((t[0], t[1], t[2]) in called for t in indels)
+    assert sum("is skipped" in r.getMessage() for r in caplog.records) >= len(indels) - 1
+    calign.closeDevice()

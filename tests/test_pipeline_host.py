@@ -135,6 +135,22 @@ def test_standard_form_moves_indels_left():
     kept = pipeline.filterVariants(sorted([Variant(b"c", t0 + 1, b"", b"T", 1, 1, 60, 30, 5),
                                            Variant(b"c", t0 + 6, b"", b"T", 1, 0, 60, 30, 7)]), fa, 150, 2, 0, 250)
     assert len(kept) == 1 and (kept[0].refPos, kept[0].nSupportingReads, kept[0].nFwdReads, kept[0].nRevReads) == (t0 - 1, 2, 1, 1)
+    # ... but only NEIGHBOURS of the sorted list merge (variantFilter.pyx:44): with another candidate between
+    # the two spellings each is judged on its own support, whether that candidate is in the list (first call)
+    # or was left out early for its low support and is known by its position only (second call)
+    mk = lambda sup: [Variant(b"c", t0 + 1, b"", b"T", sup, 1, 60, 30, 5), Variant(b"c", t0 + 6, b"", b"T", sup, 0, 60, 30, 7)]
+    weak = Variant(b"c", t0 + 3, ref[t0 + 3:t0 + 4], b"G", 1, 1, 60, 30, 5)
+    assert pipeline.filterVariants(sorted(mk(1) + [weak]), fa, 150, 2, 0, 250) == []
+    assert pipeline.filterVariants(sorted(mk(1)), fa, 150, 2, 0, 250, separators=[t0 + 3]) == []
+    assert len(pipeline.filterVariants(sorted(mk(1)), fa, 150, 2, 0, 250, separators=[t0 - 40, t0 + 60])) == 1   # none between
+    strong = Variant(b"c", t0 + 3, ref[t0 + 3:t0 + 4], b"G", 5, 3, 60, 30, 5)
+    kept = pipeline.filterVariants(sorted(mk(1) + [strong]), fa, 150, 2, 0, 250)
+    assert [(v.refPos, v.added) for v in kept] == [(t0 + 3, b"G")]
+    # both spellings pass on their own: the reference's list holds the standard form twice and its set keeps one
+    for kw, extra in ((dict(separators=[t0 + 3]), []), ({}, [weak])):
+        kept = pipeline.filterVariants(sorted(mk(2) + extra), fa, 150, 2, 0, 250, **kw)
+        assert [(v.refPos, v.nSupportingReads) for v in kept] == [(t0 - 1, 2), (t0 - 1, 2)]
+        assert [(v.refPos, v.nSupportingReads) for v in sorted(dict.fromkeys(kept))] == [(t0 - 1, 2)]
 
 
 def test_windows_and_haplotype_enumeration():
@@ -197,7 +213,8 @@ def test_early_snp_support_cut_changes_nothing():
         gen = VariantCandidateGenerator((b"sim", 0, 30000), fa)
         gen.addCandidatesFromBuffer(buf)
         raw = gen.getCandidates(cut)
-        kept = pipeline.filterVariants(raw, fa, 100, 2, 0, 250)
+        assert (len(gen.droppedSnpPositions) > 0) == (cut > 0)
+        kept = pipeline.filterVariants(raw, fa, 100, 2, 0, 250, separators=gen.droppedSnpPositions)
         lists.append((len(raw), [(v.refPos, v.removed, v.added, v.nSupportingReads, v.nFwdReads, v.nFwdReadsWeighted,
                                   v.nRevReadsWeighted, v.rmsReadPos) for v in kept]))
     assert lists[0][1] == lists[1][1] and len(lists[0][1]) > 100
