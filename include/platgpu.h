@@ -15,6 +15,7 @@
 #ifndef PLATGPU_H
 #define PLATGPU_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -60,6 +61,16 @@ int pg_ctx_destroy(pg_ctx *ctx);
 
 /* Text of the last error of this context (or of creation when ctx is NULL). */
 const char *pg_last_error_string(const pg_ctx *ctx);
+
+/*
+ * Page-locked host memory for the buffers a caller hands to pg_*_upload and
+ * pg_results_fetch / pg_caller_fetch: transfers from and to such memory run at
+ * the full PCIe rate (pageable memory goes through a staging copy at about a
+ * third of it).  Optional: every entry point takes any host memory.  No
+ * counterpart in the reference (it has no device).
+ */
+int pg_host_alloc(size_t bytes, void **out);
+int pg_host_free(void *p);
 
 /*
  * Alignment parameters: the arguments platypus/chaplotype.pyx:264 passes down

@@ -443,6 +443,20 @@ int pg_ctx_destroy(pg_ctx* c) {
     return PG_OK;
 }
 
+int pg_host_alloc(size_t bytes, void** out) {
+    if (!out) return PG_ERR_INVALID;
+    *out = nullptr;
+    if (bytes == 0) return PG_OK;
+    hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) { *out = nullptr; return fail(nullptr, PG_ERR_HIP, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
+    return PG_OK;
+}
+
+int pg_host_free(void* p) {
+    if (!p) return PG_OK;
+    return hipHostFree(p) == hipSuccess ? PG_OK : fail(nullptr, PG_ERR_HIP, "hipHostFree failed");
+}
+
 int pg_set_params(pg_ctx* c, int gapextend, int nucprior, const char* table, int table_len) {
     if (!c) return PG_ERR_INVALID;
     if (!table || table_len < 1 || table_len > pg::kMaxRun + 1)

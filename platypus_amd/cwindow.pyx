@@ -248,6 +248,18 @@ cdef class bamReadBuffer:
                 free(self.cReads[i])
             free(self.cReads)
 
+    def readArrays(self):
+        """(pos, end, mapq, isReverse, sequences, qualities) of all buffered reads as Python lists -- for tests
+        that hand the buffer's content to another implementation"""
+        cdef int i
+        cdef cAlignedRead* r
+        pos, end, mapq, rev, seqs, quals = [], [], [], [], [], []
+        for i in range(self.nReads):
+            r = self.cReads[i]
+            pos.append(r.pos); end.append(r.end); mapq.append(r.mapq); rev.append(bool(r.isReverse))
+            seqs.append(r.seq[:r.rlen]); quals.append(r.qual[:r.rlen])
+        return pos, end, mapq, rev, seqs, quals
+
     def readInfo(self, int i):
         """(pos, end, rlen, mapq, isReverse, qualities) of buffered read i -- for tests"""
         cdef cAlignedRead* r = self.cReads[i]

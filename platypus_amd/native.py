@@ -5,6 +5,7 @@ module raises -- there is no Python or CPU fallback for the alignment path.
 """
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -26,6 +27,8 @@ SYMBOLS = {
     "pg_ctx_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "pg_ctx_destroy": (C.c_int, [C.c_void_p]),
     "pg_last_error_string": (C.c_char_p, [C.c_void_p]),
+    "pg_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "pg_host_free": (C.c_int, [C.c_void_p]),
     "pg_set_params": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_int]),
     "pg_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
     "pg_haps_upload": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _i64p, _i32p, _i32p]),
@@ -80,6 +83,23 @@ def _ptr(a):
 def _arr(a, dtype):
     a = np.ascontiguousarray(a, dtype=dtype)
     return a
+
+
+def pinned_array(shape, dtype):
+    """numpy array in page-locked host memory (pg_host_alloc); freed when the array and its views are gone"""
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape))
+    p = C.c_void_p()
+    rc = LIB.pg_host_alloc(max(1, n * dtype.itemsize), C.byref(p))
+    if rc != PG_OK:
+        raise PlatGpuError(rc, (LIB.pg_last_error_string(None) or b"").decode())
+    buf = (C.c_char * max(1, n * dtype.itemsize)).from_address(p.value)
+    a = np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
+    _PINNED[p.value] = (buf, weakref.finalize(a.base if a.base is not None else a, LIB.pg_host_free, p.value))
+    return a
+
+
+_PINNED = {}
 
 
 class AlignContext(object):

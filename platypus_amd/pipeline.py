@@ -258,10 +258,10 @@ def binomial(x, size, prob):
         return 1.0
     if x == 0 and size == 0:
         return 1.0
-    if prob <= 0.0 or size < x:
+    if prob <= 0.0:                                                   # x > 0 here: exp(x * log(0)) of the C library
         return 0.0
-    return math.exp(logFactorial(size) - (logFactorial(x) + logFactorial(size - x)) + x * math.log(prob)
-                    + (size - x) * math.log(1.0 - prob))
+    return math.exp((logFactorial(size) - (logFactorial(x) + logFactorial(size - x))) +
+                    (x * math.log(prob) + (size - x) * math.log(1.0 - prob)))
 
 
 @functools.lru_cache(maxsize=1 << 16)
@@ -285,11 +285,15 @@ def homopolymerLength(variant, refFile):
     return max(nl, nr) if left[-1:] != right[:1] else nl + nr
 
 
-def siteStatistics(batch, k, variant, freq, refFile, options, minQuals):
+def siteStatistics(batch, k, variant, freq, refFile, options, minQuals, fwdWeight):
     """INFO statistics of one variant (cpopulation.pyx:239-389, chaplotype.pyx:412-432).  `minQuals` is the
     window's running list of minimum base qualities: the reference never clears it between the variants
-    of a window (cpopulation.pyx:231,310), so neither is it cleared here."""
+    of a window (cpopulation.pyx:231,310), so neither is it cleared here.  `fwdWeight` (a one-element list)
+    is the window's running weighted forward coverage: the reference resets it under a misspelt name
+    (cpopulation.pyx:269), so every variant's forward p-value sees the sum over the variants before it too."""
     tc, tcr, tcf, wr, wf, mins = batch.siteStatistics(k, variant.refPos, variant.added, options.badReadsWindow)
+    fwdWeight[0] += wf
+    wf = fwdWeight[0]
     minQuals.extend(mins)
     minQuals.sort()
     med = minQuals[len(minQuals) // 2] if minQuals else 100
@@ -458,14 +462,14 @@ def callRegion(chrom, start, end, readBuffers, refFile, options=None, variants=N
         if not byPos:                                                 # nothing of this window is written: no statistics needed
             continue
         freqs = pop.frequenciesPy()
-        minQuals, stats_list = [], []
+        minQuals, fwdWeight, stats_list = [], [0.0], []
         all_vars = {}
         for hap in pop.haplotypes:                                    # INFO and FILTER cover every haplotype's variants
             for v in hap.variantsPy():
                 all_vars[v] = v
         for v in sorted(all_vars, key=lambda v: v._key()):
             fr = sum(f for f, hap in zip(freqs, pop.haplotypes) if v in hap.variantsPy())
-            stats_list.append((v, siteStatistics(batch, k, v, fr, refFile, options, minQuals)))
+            stats_list.append((v, siteStatistics(batch, k, v, fr, refFile, options, minQuals, fwdWeight)))
         win_flags = windowFilters(stats_list, options)
         stats_of = {v: st for v, st in stats_list}
         last_var = stats_list[-1][0] if stats_list else None

@@ -80,5 +80,5 @@ def record(call, refFile):
             str(call.qual), ";".join(call.filters) if call.filters else "PASS", info_text, "GT:GL:GQ:NR"]
     for i in range(len(call.GT)):
         cols.append("%s:%s:%s:%s" % (call.GT[i], ",".join(str(x) for x in call.GL[i]),
-                                     "." if call.GQ[i] == -1 else call.GQ[i], call.nReads[i]))
+                                     call.GQ[i], call.nReads[i]))     # -1 is written as it is: GQ's missing value is "."
     return "\t".join(cols)

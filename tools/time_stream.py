@@ -1,0 +1,88 @@
+"""PCIe-inclusive rate of the hot path: batches streamed through the C ABI from host memory to results on the
+host, two contexts (one stream each) taking turns so that one batch's transfers overlap the other's kernels.
+
+    python tools/time_stream.py [windows per batch] [batches] [pinned 0/1]
+
+Every batch is uploaded in full (haplotypes, reads, block descriptors), launched and fetched (score, anchor,
+likelihood): nothing stays resident between batches.  Prints wall time per batch and GCUPS."""
+import ctypes as C
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+from platypus_amd import native, synth  # noqa: E402
+
+W = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+pinned = (int(sys.argv[3]) if len(sys.argv) > 3 else 1) != 0
+H, R, L = 4, 32, 150
+b = synth.make_batch(n_windows=W, haps_per_window=H, reads_per_window=R, read_len=L)
+n_pairs = W * H * R
+
+
+def host(a):
+    if not pinned:
+        return np.ascontiguousarray(a)
+    p = native.pinned_array(a.shape, a.dtype)
+    p[...] = a
+    return p
+
+
+src = {k: host(b[k]) for k in ("hap_seq", "hap_off", "hap_start", "hap_varlen", "read_seq", "read_qual", "read_off",
+                               "read_pos", "read_mapq")}
+blk = dict(hap_lo=np.arange(W, dtype=np.int32) * H, n_haps=np.full(W, H, np.int32),
+           read_lo=np.arange(W, dtype=np.int32) * R, n_reads=np.full(W, R, np.int32))
+ctxs = [native.AlignContext(0), native.AlignContext(0)]
+outs = [(host(np.empty(n_pairs, np.int32)), host(np.empty(n_pairs, np.int32)), host(np.empty(n_pairs, np.float64)))
+        for _ in ctxs]
+
+
+def upload_and_launch(c):
+    c.upload_haps(src["hap_seq"], src["hap_off"], src["hap_start"], src["hap_varlen"])
+    c.upload_reads(src["read_seq"], src["read_qual"], src["read_off"], src["read_pos"], src["read_mapq"])
+    c.pairs_blocks(blk["hap_lo"], blk["n_haps"], blk["read_lo"], blk["n_reads"])
+    c.launch()                                   # asynchronous: the kernels run while the other context uploads
+
+
+def fetch(c, o):
+    c._check(native.LIB.pg_results_fetch(c._h, o[0].ctypes.data, o[1].ctypes.data, o[2].ctypes.data))
+
+
+# the link itself: one large copy from page-locked memory, to put the batch rate beside
+hip = C.CDLL("libamdhip64.so.7")
+hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+hip.hipFree.argtypes = [C.c_void_p]
+probe = native.pinned_array((256 << 20,), np.uint8)
+probe[...] = 1
+dev = C.c_void_p()
+assert hip.hipMalloc(C.byref(dev), probe.nbytes) == 0
+link = []
+for rep in range(4):
+    t0 = time.perf_counter()
+    assert hip.hipMemcpy(dev, probe.ctypes.data, probe.nbytes, 1) == 0
+    link.append(probe.nbytes / (time.perf_counter() - t0) / 1e9)
+hip.hipFree(dev)
+print("host-to-device copy of 256 MiB from page-locked memory: %.1f GB/s" % max(link[1:]))
+
+for warm in range(2):
+    for c, o in zip(ctxs, outs):
+        upload_and_launch(c)
+        fetch(c, o)
+ref = [x.copy() for x in outs[0]]
+t0 = time.perf_counter()
+upload_and_launch(ctxs[0])
+for k in range(1, N):
+    upload_and_launch(ctxs[k & 1])               # batch k goes up while batch k - 1 is computed
+    fetch(ctxs[(k - 1) & 1], outs[(k - 1) & 1])
+fetch(ctxs[(N - 1) & 1], outs[(N - 1) & 1])
+dt = (time.perf_counter() - t0) / N
+assert all(np.array_equal(x, y) for x, y in zip(outs[0], ref)) and all(np.array_equal(x, y) for x, y in zip(outs[1], ref))
+up = sum(src[k].nbytes for k in src) + sum(v.nbytes for v in blk.values())
+print("%s host memory, %d batches of %d pairs: %.2f ms per batch = %.0f GCUPS (%.1f M pairs/s); up %.0f MB (%.1f GB/s if "
+      "transfers alone filled the time), down %.0f MB" % ("pinned" if pinned else "pageable", N, n_pairs, dt * 1e3,
+                                                          n_pairs * 16 * (L + 8) / dt / 1e9, n_pairs / dt / 1e6, up / 1e6,
+                                                          up / dt / 1e9, n_pairs * 16 / 1e6))

@@ -5,6 +5,12 @@ import numpy as np
 from platypus_amd import native, synth
 
 b = synth.make_batch(n_windows=int(sys.argv[1]) if len(sys.argv) > 1 else 32768)
+if len(sys.argv) > 2 and sys.argv[2] == "pinned":          # the caller's buffers in page-locked memory (pg_host_alloc)
+    for k in list(b):
+        if isinstance(b[k], np.ndarray):
+            p = native.pinned_array(b[k].shape, b[k].dtype)
+            p[...] = b[k]
+            b[k] = p
 ctx = native.AlignContext(0)
 for rep in range(3):
     t = [time.perf_counter()]
