@@ -140,6 +140,7 @@ def main():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-e2e", action="store_true", help="skip the file-to-file end-to-end leg")
+    ap.add_argument("--no-stream", action="store_true", help="skip the PCIe-inclusive (streamed batches) leg")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="kernel-choice override passed to pg_set_option (measurement sweeps)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="wgs",
@@ -288,6 +289,20 @@ def main():
     except native.PlatGpuError as e:                       # reported, never hidden
         caller = {"error": str(e)}
 
+    # ---- PCIe-inclusive rate, never `value`: the same batch streamed from page-locked host memory through the
+    # ABI (everything uploaded and fetched per batch, two contexts taking turns), beside the link's own rate ----
+    streamed = None
+    if world == 1 and not args.no_stream and args.workload == "wgs":
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import time_stream
+            streamed = time_stream.measure(W=n_windows, N=8, pinned=True, device=device, batch=batch)
+            streamed["link_gbps"] = time_stream.link_rate()
+            streamed["what"] = ("haplotypes, reads and window blocks uploaded, kernels run, score / anchor / likelihood "
+                                "fetched for every batch; bytes_up / link_gbps is the least a batch can take")
+        except Exception as e:                             # reported, never hidden
+            streamed = {"error": "%s: %s" % (type(e).__name__, e)}
+
     # ---- file to file (simulated BAM + FASTA -> VCF through the region caller), not part of the metric:
     # the second figure BASELINE.json names, Mbp/min, for ONE process / one GPU -------------------------
     e2e = None
@@ -334,6 +349,8 @@ def main():
         "roofline_anchor": roofline_anchor,
         "cpu_baseline": cpu,
         "caller_stage": caller,
+        "pcie_inclusive": streamed,
+        "pcie_inclusive_gcups": streamed.get("gcups") if streamed else None,
         "end_to_end": e2e,
     }
     print(json.dumps(out), flush=True)

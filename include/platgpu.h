@@ -167,6 +167,15 @@ int pg_sync(pg_ctx *ctx);
  */
 int pg_results_fetch(pg_ctx *ctx, int32_t *score, int32_t *anchor, double *likelihood);
 
+/*
+ * The same copies enqueued on the context's stream without waiting: the outputs
+ * are complete after the next pg_sync (or any later synchronising call) on this
+ * context.  With outputs in page-locked memory (pg_host_alloc) the transfer runs
+ * beside whatever the host does next -- another context's uploads, say; into
+ * pageable memory the HIP runtime may wait before it returns.
+ */
+int pg_results_fetch_async(pg_ctx *ctx, int32_t *score, int32_t *anchor, double *likelihood);
+
 /* upload pairs + launch + sync + fetch in one call */
 int pg_align_pairs(pg_ctx *ctx, int64_t n_pairs, const int32_t *hap_idx, const int32_t *read_idx,
                    int32_t *score, int32_t *anchor, double *likelihood);

@@ -204,4 +204,90 @@ __global__ __launch_bounds__(256) void k_prep_waves(const PrepArgs A, int wave_b
     A.W.waves[w] = WaveDesc{A.W.len_slot[lo] + 64 * k, min(64, c - 64 * k), lo, 0};
 }
 
+// ---------------------------------------------------------------------------
+// Upload bookkeeping on the device: the offset arrays of a read batch are derived
+// from the caller's offsets by kernels, so the host never walks the reads either.
+//   k_read_meta   per read: length, offset relative to the first read, the sizes of its
+//                 element row and of its packed row; validates length and mapping quality;
+//                 longest and shortest read
+//   scan64_*      inclusive prefix sums of an int64 array in place (three passes)
+// meta words: [0] flags (1 a length outside 1..max, 2 a mapping quality outside 0..255),
+// [1] longest read, [2] shortest read, [3] first offending read
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_read_meta(const int64_t* __restrict__ off, const int32_t* __restrict__ mapq, int n,
+                                                   int max_read_len, int64_t* __restrict__ roff, int32_t* __restrict__ rlen,
+                                                   int64_t* __restrict__ xoff, int64_t* __restrict__ off2,
+                                                   int32_t* __restrict__ meta)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int64_t o0 = off[0];
+    int lmax = 0, lmin = 0x7fffffff;
+    if (i == 0) { xoff[0] = 0; off2[0] = 0; roff[n] = off[n] - o0; }
+    if (i < n) {
+        const int64_t l = off[i + 1] - off[i];
+        const bool bad_len = l < 1 || l > max_read_len, bad_mq = mapq[i] < 0 || mapq[i] > 255;
+        if (bad_len || bad_mq) { atomicOr(&meta[0], bad_len ? 1 : 2); atomicMin(&meta[3], i); }
+        const int len = bad_len ? 1 : (int)l;
+        roff[i] = off[i] - o0;
+        rlen[i] = len;
+        xoff[i + 1] = ((len + 7) / 8) * 8 + 24;        // 8-element aligned rows with >= 24 padding elements
+        off2[i + 1] = (len + 15) / 16 + 2;             // packed 2-bit rows end with two zero words
+        lmax = lmin = len;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { lmax = max(lmax, __shfl_xor(lmax, o)); lmin = min(lmin, __shfl_xor(lmin, o)); }
+    if ((threadIdx.x & 63) == 0 && lmax > 0) { atomicMax(&meta[1], lmax); atomicMin(&meta[2], lmin); }
+}
+
+constexpr int kScanBlock = 4096;                        // elements per workgroup of the scan passes
+
+__global__ __launch_bounds__(1024) void scan64_local(int64_t* __restrict__ a, int64_t n, int64_t* __restrict__ tops)
+{
+    __shared__ int64_t s[1024];
+    const int tid = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * kScanBlock + 4 * tid;
+    int64_t v[4], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[k] = base + k < n ? a[base + k] : 0; sum += v[k]; v[k] = sum; }
+    s[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int64_t t = tid >= o ? s[tid - o] : 0;
+        __syncthreads();
+        s[tid] += t;
+        __syncthreads();
+    }
+    const int64_t before = s[tid] - sum;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (base + k < n) a[base + k] = before + v[k];
+    if (tid == 1023) tops[blockIdx.x] = s[1023];
+}
+
+__global__ __launch_bounds__(1024) void scan64_tops(int64_t* __restrict__ tops, int nb)   // exclusive, one workgroup
+{
+    __shared__ int64_t s[1024];
+    const int tid = threadIdx.x;
+    const int chunk = (nb + 1023) / 1024, lo = min(nb, tid * chunk), hi = min(nb, lo + chunk);
+    int64_t sum = 0;
+    for (int i = lo; i < hi; ++i) sum += tops[i];
+    s[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int64_t t = tid >= o ? s[tid - o] : 0;
+        __syncthreads();
+        s[tid] += t;
+        __syncthreads();
+    }
+    int64_t run = s[tid] - sum;
+    for (int i = lo; i < hi; ++i) { const int64_t t = tops[i]; tops[i] = run; run += t; }
+}
+
+__global__ __launch_bounds__(1024) void scan64_add(int64_t* __restrict__ a, int64_t n, const int64_t* __restrict__ tops)
+{
+    const int64_t add = tops[blockIdx.x];
+    const int64_t base = (int64_t)blockIdx.x * kScanBlock + 4 * threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (base + k < n) a[base + k] += add;
+}
+
 }  // namespace pg

@@ -129,7 +129,7 @@ struct pg_ctx {
     DevBuf<int32_t> d_read_len;
     DevBuf<uint8_t> d_rseq, d_rqual;
     DevBuf<uint16_t> d_readx;
-    DevBuf<int64_t> d_roff, d_read_xoff, d_read2off;
+    DevBuf<int64_t> d_roff, d_read_xoff, d_read2off, d_off_in, d_scan_tops;
     DevBuf<uint32_t> d_read2;           // 2-bit packed bases
     DevBuf<int32_t> d_read_pos, d_read_mapq, d_flag;
 
@@ -429,7 +429,7 @@ int pg_ctx_destroy(pg_ctx* c) {
     c->d_pair_hap.release(); c->d_pair_read.release(); c->d_order.release();
     c->d_vh.release(); c->d_anchor_in.release(); c->d_hap_vote_ord.release(); c->d_read_len.release();
     c->d_status.release(); c->d_hap_cnt.release(); c->d_hap_cur.release(); c->d_len_work.release();
-    c->d_blk32.release(); c->d_blk_base.release();
+    c->d_blk32.release(); c->d_blk_base.release(); c->d_off_in.release(); c->d_scan_tops.release();
     c->d_wins.release(); c->d_ioff.release(); c->d_em_iters.release(); c->d_best_gen.release();
     c->d_var_win.release(); c->d_cells.release(); c->d_full.release(); c->d_freq.release(); c->d_em_change.release();
     c->d_best_val.release(); c->d_var_prior.release(); c->d_var_out.release(); c->d_var_moff.release(); c->d_win_max.release(); c->d_fprev.release(); c->d_share.release(); c->d_em_done.release(); c->d_share_base.release(); c->d_rows.release(); c->d_cmp_bytes.release(); c->d_cmp_ints.release(); c->d_var_mask.release(); c->d_vh_recs.release(); c->d_waves.release(); c->d_score.release(); c->d_anchor.release(); c->d_like.release();
@@ -586,59 +586,62 @@ int pg_reads_upload(pg_ctx* c, int n, const char* seq, const char* qual, const i
     PG_HIP(c, hipSetDevice(c->device));
     c->n_reads = 0; c->n_pairs = 0; c->launched = false;
     if (n == 0) return PG_OK;
-    int maxl = 0, minl = 1 << 30;
-    for (int i = 0; i < n; ++i) {
-        const int64_t l = off[i + 1] - off[i];
-        if (l < 1 || l > c->max_read_len)
-            return fail(c, PG_ERR_UNSUPPORTED, "read %d has length %lld; this context takes 1..%d", i, (long long)l, c->max_read_len);
-        if (mapq[i] < 0 || mapq[i] > 255)
-            return fail(c, PG_ERR_UNSUPPORTED, "read %d has mapping quality %d outside 0..255", i, mapq[i]);
-        maxl = std::max(maxl, (int)l);
-        minl = std::min(minl, (int)l);
-    }
     const int64_t total = off[n] - off[0];
+    if (total < n) return fail(c, PG_ERR_UNSUPPORTED, "%d reads in %lld bases: reads must hold 1..%d bases", n, (long long)total, c->max_read_len);
+    // The host touches the two ends of `off` only: lengths, the offsets of the element and packed rows, the
+    // longest and shortest read and the validity of lengths and mapping qualities are worked out on the device.
+    // Element and packed arrays are sized by what n reads of `total` bases can need at most.
+    const size_t x_bound = (size_t)total + (size_t)n * 31 + 64, w_bound = (size_t)total / 16 + (size_t)n * 3 + 16;
+    const int nb = (n + pg::kScanBlock - 1) / pg::kScanBlock;
     PG_HIP(c, c->d_flag.reserve(64));
-    PG_HIP(c, hipMemsetAsync(c->d_flag.p, 0, 64 * sizeof(int32_t), c->stream));
     PG_HIP(c, c->d_rseq.reserve((size_t)total + 64));
     PG_HIP(c, c->d_rqual.reserve((size_t)total + 64));
-    PG_HIP(c, c->d_roff.reserve(n + 1));
+    PG_HIP(c, c->d_roff.reserve((size_t)n + 1));
+    PG_HIP(c, c->d_off_in.reserve((size_t)n + 1));
     PG_HIP(c, c->d_read_pos.reserve(n));
     PG_HIP(c, c->d_read_mapq.reserve(n));
-    std::vector<int64_t> roff(n + 1), xoff(n + 1);
-    std::vector<int32_t> rlen(n);
-    for (int i = 0; i <= n; ++i) roff[i] = off[i] - off[0];
-    for (int i = 0; i < n; ++i) rlen[i] = (int32_t)(roff[i + 1] - roff[i]);
     PG_HIP(c, c->d_read_len.reserve(n));
-    PG_HIP(c, hipMemcpyAsync(c->d_read_len.p, rlen.data(), n * 4, hipMemcpyHostToDevice, c->stream));
-    xoff[0] = 0;                                   // 8-element aligned rows with >= 24 padding elements
-    for (int i = 0; i < n; ++i) xoff[i + 1] = xoff[i] + ((roff[i + 1] - roff[i] + 7) / 8) * 8 + 24;
-    PG_HIP(c, c->d_readx.reserve((size_t)xoff[n] + 64));
-    PG_HIP(c, c->d_read_xoff.reserve(n + 1));
-    PG_HIP(c, hipMemcpyAsync(c->d_read_xoff.p, xoff.data(), (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    PG_HIP(c, c->d_readx.reserve(x_bound));
+    PG_HIP(c, c->d_read_xoff.reserve((size_t)n + 1));
+    PG_HIP(c, c->d_read2.reserve(w_bound));
+    PG_HIP(c, c->d_read2off.reserve((size_t)n + 1));
+    PG_HIP(c, c->d_scan_tops.reserve(2 * (size_t)nb + 2));
+    static const int32_t kMeta0[8] = {0, 0, 0x7fffffff, 0x7fffffff, 0, 0, 0, 0};   // d_flag[0..7]: pack flags; [8..15]: meta
+    PG_HIP(c, hipMemsetAsync(c->d_flag.p, 0, 8 * sizeof(int32_t), c->stream));
+    PG_HIP(c, hipMemcpyAsync(c->d_flag.p + 8, kMeta0, sizeof kMeta0, hipMemcpyHostToDevice, c->stream));
+    PG_HIP(c, hipMemcpyAsync(c->d_off_in.p, off, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    PG_HIP(c, hipMemcpyAsync(c->d_read_mapq.p, mapq, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    PG_HIP(c, hipMemcpyAsync(c->d_read_pos.p, pos, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(pg::k_read_meta, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_off_in.p, c->d_read_mapq.p, n,
+                       c->max_read_len, c->d_roff.p, c->d_read_len.p, c->d_read_xoff.p, c->d_read2off.p, c->d_flag.p + 8);
+    for (int which = 0; which < 2; ++which) {          // row sizes -> row offsets
+        int64_t* a = (which == 0 ? c->d_read_xoff.p : c->d_read2off.p) + 1;
+        int64_t* tops = c->d_scan_tops.p + (size_t)which * (nb + 1);
+        hipLaunchKernelGGL(pg::scan64_local, dim3(nb), dim3(1024), 0, c->stream, a, (int64_t)n, tops);
+        hipLaunchKernelGGL(pg::scan64_tops, dim3(1), dim3(1024), 0, c->stream, tops, nb);
+        hipLaunchKernelGGL(pg::scan64_add, dim3(nb), dim3(1024), 0, c->stream, a, (int64_t)n, tops);
+    }
+    PG_HIP(c, hipGetLastError());
     PG_HIP(c, hipMemcpyAsync(c->d_rseq.p, seq + off[0], (size_t)total, hipMemcpyHostToDevice, c->stream));
     PG_HIP(c, hipMemcpyAsync(c->d_rqual.p, qual + off[0], (size_t)total, hipMemcpyHostToDevice, c->stream));
-    PG_HIP(c, hipMemcpyAsync(c->d_roff.p, roff.data(), (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    PG_HIP(c, hipMemcpyAsync(c->d_read_pos.p, pos, n * 4, hipMemcpyHostToDevice, c->stream));
-    PG_HIP(c, hipMemcpyAsync(c->d_read_mapq.p, mapq, n * 4, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(pg::k_pack_readx, dim3(std::min((n + 3) / 4, 65536)), dim3(256), 0, c->stream, c->d_rseq.p,
                        c->d_rqual.p, c->d_roff.p, c->d_read_xoff.p, c->d_readx.p, c->d_codes.p, n, c->d_flag.p);
-    PG_HIP(c, hipGetLastError());
-    std::vector<int64_t> off2(n + 1);
-    off2[0] = 0;
-    for (int i = 0; i < n; ++i) off2[i + 1] = off2[i] + (roff[i + 1] - roff[i] + 15) / 16 + 2;
-    PG_HIP(c, c->d_read2.reserve((size_t)off2[n] + 16));
-    PG_HIP(c, c->d_read2off.reserve(n + 1));
-    PG_HIP(c, hipMemcpyAsync(c->d_read2off.p, off2.data(), (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(pg::k_pack_codes, dim3(std::min((n + 3) / 4, 65536)), dim3(256), 0, c->stream, c->d_rseq.p,
                        c->d_roff.p, c->d_read2off.p, c->d_read2.p, n);
     PG_HIP(c, hipGetLastError());
-    int32_t bad = 0;
-    PG_HIP(c, hipMemcpyAsync(&bad, c->d_flag.p, sizeof bad, hipMemcpyDeviceToHost, c->stream));
+    PG_HIP(c, hipMemcpyAsync(c->h_status, c->d_flag.p, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     PG_HIP(c, hipStreamSynchronize(c->stream));
-    if (bad & 1) return fail(c, PG_ERR_UNSUPPORTED, "a base quality above 127 was found");
-    if (bad & 2) return fail(c, PG_ERR_UNSUPPORTED, "a read holds a byte outside 1..31, 33..126");
-    c->max_rlen = maxl;
-    c->uniform_rlen = (maxl == minl);
+    const int32_t* st = c->h_status;
+    if (st[8] & 1) {
+        const int i = st[11];
+        return fail(c, PG_ERR_UNSUPPORTED, "read %d has length %lld; this context takes 1..%d", i,
+                    (long long)(off[i + 1] - off[i]), c->max_read_len);
+    }
+    if (st[8] & 2) return fail(c, PG_ERR_UNSUPPORTED, "read %d has mapping quality %d outside 0..255", st[11], mapq[st[11]]);
+    if (st[0] & 1) return fail(c, PG_ERR_UNSUPPORTED, "a base quality above 127 was found");
+    if (st[0] & 2) return fail(c, PG_ERR_UNSUPPORTED, "a read holds a byte outside 1..31, 33..126");
+    c->max_rlen = st[9];
+    c->uniform_rlen = (st[9] == st[10]);
     c->n_reads = n;
     return PG_OK;
 }
@@ -723,7 +726,7 @@ int pg_sync(pg_ctx* c) {
     return PG_OK;
 }
 
-int pg_results_fetch(pg_ctx* c, int32_t* score, int32_t* anchor, double* like) {
+int pg_results_fetch_async(pg_ctx* c, int32_t* score, int32_t* anchor, double* like) {
     if (!c) return PG_ERR_INVALID;
     if (!c->launched) return fail(c, PG_ERR_STATE, "nothing launched");
     PG_HIP(c, hipSetDevice(c->device));
@@ -731,6 +734,12 @@ int pg_results_fetch(pg_ctx* c, int32_t* score, int32_t* anchor, double* like) {
     if (score) PG_HIP(c, hipMemcpyAsync(score, c->d_score.p, n * 4, hipMemcpyDeviceToHost, c->stream));
     if (anchor) PG_HIP(c, hipMemcpyAsync(anchor, c->d_anchor.p, n * 4, hipMemcpyDeviceToHost, c->stream));
     if (like) PG_HIP(c, hipMemcpyAsync(like, c->d_like.p, n * 8, hipMemcpyDeviceToHost, c->stream));
+    return PG_OK;
+}
+
+int pg_results_fetch(pg_ctx* c, int32_t* score, int32_t* anchor, double* like) {
+    int rc = pg_results_fetch_async(c, score, anchor, like);
+    if (rc != PG_OK) return rc;
     PG_HIP(c, hipStreamSynchronize(c->stream));
     return PG_OK;
 }

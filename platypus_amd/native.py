@@ -39,6 +39,7 @@ SYMBOLS = {
     "pg_align_launch": (C.c_int, [C.c_void_p]),
     "pg_sync": (C.c_int, [C.c_void_p]),
     "pg_results_fetch": (C.c_int, [C.c_void_p, _i32p, _i32p, _f64p]),
+    "pg_results_fetch_async": (C.c_int, [C.c_void_p, _i32p, _i32p, _f64p]),
     "pg_align_pairs": (C.c_int, [C.c_void_p, C.c_int64, _i32p, _i32p, _i32p, _i32p, _f64p]),
     "pg_align_pairs_noalloc": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pg_kernel_time_ms": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),

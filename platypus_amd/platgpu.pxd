@@ -12,6 +12,7 @@ cdef extern from "platgpu.h":
     const char* pg_last_error_string(const pg_ctx* ctx)
     int pg_set_params(pg_ctx* ctx, int gapextend, int nucprior, const char* table, int table_len)
     int pg_set_option(pg_ctx* ctx, const char* name, const char* value)
+    int pg_results_fetch_async(pg_ctx* ctx, int32_t* score, int32_t* anchor, double* likelihood)
     int pg_host_alloc(size_t bytes, void** out)
     int pg_host_free(void* p)
     int pg_align_pairs_noalloc(pg_ctx* ctx, int64_t n_pairs, const int32_t* d_hap_idx, const int32_t* d_read_idx,

@@ -15,74 +15,93 @@ import numpy as np  # noqa: E402
 
 from platypus_amd import native, synth  # noqa: E402
 
-W = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
-N = int(sys.argv[2]) if len(sys.argv) > 2 else 12
-pinned = (int(sys.argv[3]) if len(sys.argv) > 3 else 1) != 0
 H, R, L = 4, 32, 150
-b = synth.make_batch(n_windows=W, haps_per_window=H, reads_per_window=R, read_len=L)
-n_pairs = W * H * R
 
 
-def host(a):
-    if not pinned:
-        return np.ascontiguousarray(a)
-    p = native.pinned_array(a.shape, a.dtype)
-    p[...] = a
-    return p
+def link_rate():
+    """GB/s of one 256-MiB copy from page-locked host memory to the device: the ceiling of any upload"""
+    hip = C.CDLL("libamdhip64.so.7")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    probe = native.pinned_array((256 << 20,), np.uint8)
+    probe[...] = 1
+    dev = C.c_void_p()
+    assert hip.hipMalloc(C.byref(dev), probe.nbytes) == 0
+    rates = []
+    for rep in range(4):
+        t0 = time.perf_counter()
+        assert hip.hipMemcpy(dev, probe.ctypes.data, probe.nbytes, 1) == 0
+        rates.append(probe.nbytes / (time.perf_counter() - t0) / 1e9)
+    hip.hipFree(dev)
+    return max(rates[1:])
 
 
-src = {k: host(b[k]) for k in ("hap_seq", "hap_off", "hap_start", "hap_varlen", "read_seq", "read_qual", "read_off",
-                               "read_pos", "read_mapq")}
-blk = dict(hap_lo=np.arange(W, dtype=np.int32) * H, n_haps=np.full(W, H, np.int32),
-           read_lo=np.arange(W, dtype=np.int32) * R, n_reads=np.full(W, R, np.int32))
-ctxs = [native.AlignContext(0), native.AlignContext(0)]
-outs = [(host(np.empty(n_pairs, np.int32)), host(np.empty(n_pairs, np.int32)), host(np.empty(n_pairs, np.float64)))
-        for _ in ctxs]
+def measure(W=32768, N=12, pinned=True, device=0, batch=None):
+    b = batch if batch is not None else synth.make_batch(n_windows=W, haps_per_window=H, reads_per_window=R, read_len=L)
+    n_pairs = W * H * R
+
+    def host(a):
+        if not pinned:
+            return np.ascontiguousarray(a)
+        p = native.pinned_array(a.shape, a.dtype)
+        p[...] = a
+        return p
+
+    src = {k: host(b[k]) for k in ("hap_seq", "hap_off", "hap_start", "hap_varlen", "read_seq", "read_qual", "read_off",
+                                   "read_pos", "read_mapq")}
+    blk = dict(hap_lo=np.arange(W, dtype=np.int32) * H, n_haps=np.full(W, H, np.int32),
+               read_lo=np.arange(W, dtype=np.int32) * R, n_reads=np.full(W, R, np.int32))
+    ctxs = [native.AlignContext(device), native.AlignContext(device)]
+    outs = [(host(np.empty(n_pairs, np.int32)), host(np.empty(n_pairs, np.int32)), host(np.empty(n_pairs, np.float64)))
+            for _ in ctxs]
+
+    def upload_and_launch(c):
+        c.upload_haps(src["hap_seq"], src["hap_off"], src["hap_start"], src["hap_varlen"])
+        c.upload_reads(src["read_seq"], src["read_qual"], src["read_off"], src["read_pos"], src["read_mapq"])
+        c.pairs_blocks(blk["hap_lo"], blk["n_haps"], blk["read_lo"], blk["n_reads"])
+        c.launch()                               # asynchronous: the kernels run while the other context uploads
+
+    def fetch_async(c, o):                       # enqueued behind the context's kernels; complete after c.sync()
+        c._check(native.LIB.pg_results_fetch_async(c._h, o[0].ctypes.data, o[1].ctypes.data, o[2].ctypes.data))
+
+    try:
+        for warm in range(2):
+            for c, o in zip(ctxs, outs):
+                upload_and_launch(c)
+                fetch_async(c, o)
+                c.sync()
+        ref = [x.copy() for x in outs[0]]
+        for o in outs:
+            for x in o:
+                x[...] = 0
+        t0 = time.perf_counter()
+        upload_and_launch(ctxs[0])
+        fetch_async(ctxs[0], outs[0])
+        for k in range(1, N):
+            upload_and_launch(ctxs[k & 1])       # batch k goes up while batch k - 1 is computed and comes down
+            fetch_async(ctxs[k & 1], outs[k & 1])
+            ctxs[(k - 1) & 1].sync()             # batch k - 1 is on the host now
+        ctxs[(N - 1) & 1].sync()
+        dt = (time.perf_counter() - t0) / N
+        same = all(np.array_equal(x, y) for o in outs for x, y in zip(o, ref))
+    finally:
+        for c in ctxs:
+            c.close()
+    up = sum(src[k].nbytes for k in src) + sum(v.nbytes for v in blk.values())
+    return dict(ms_per_batch=dt * 1e3, gcups=n_pairs * 16 * (L + 8) / dt / 1e9, pairs_per_s=n_pairs / dt, batches=N,
+                pairs_per_batch=n_pairs, bytes_up=up, bytes_down=n_pairs * 16, upload_gbps=up / dt / 1e9,
+                host_memory="page-locked (pg_host_alloc)" if pinned else "pageable", results_equal_across_batches=same)
 
 
-def upload_and_launch(c):
-    c.upload_haps(src["hap_seq"], src["hap_off"], src["hap_start"], src["hap_varlen"])
-    c.upload_reads(src["read_seq"], src["read_qual"], src["read_off"], src["read_pos"], src["read_mapq"])
-    c.pairs_blocks(blk["hap_lo"], blk["n_haps"], blk["read_lo"], blk["n_reads"])
-    c.launch()                                   # asynchronous: the kernels run while the other context uploads
-
-
-def fetch(c, o):
-    c._check(native.LIB.pg_results_fetch(c._h, o[0].ctypes.data, o[1].ctypes.data, o[2].ctypes.data))
-
-
-# the link itself: one large copy from page-locked memory, to put the batch rate beside
-hip = C.CDLL("libamdhip64.so.7")
-hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
-hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-hip.hipFree.argtypes = [C.c_void_p]
-probe = native.pinned_array((256 << 20,), np.uint8)
-probe[...] = 1
-dev = C.c_void_p()
-assert hip.hipMalloc(C.byref(dev), probe.nbytes) == 0
-link = []
-for rep in range(4):
-    t0 = time.perf_counter()
-    assert hip.hipMemcpy(dev, probe.ctypes.data, probe.nbytes, 1) == 0
-    link.append(probe.nbytes / (time.perf_counter() - t0) / 1e9)
-hip.hipFree(dev)
-print("host-to-device copy of 256 MiB from page-locked memory: %.1f GB/s" % max(link[1:]))
-
-for warm in range(2):
-    for c, o in zip(ctxs, outs):
-        upload_and_launch(c)
-        fetch(c, o)
-ref = [x.copy() for x in outs[0]]
-t0 = time.perf_counter()
-upload_and_launch(ctxs[0])
-for k in range(1, N):
-    upload_and_launch(ctxs[k & 1])               # batch k goes up while batch k - 1 is computed
-    fetch(ctxs[(k - 1) & 1], outs[(k - 1) & 1])
-fetch(ctxs[(N - 1) & 1], outs[(N - 1) & 1])
-dt = (time.perf_counter() - t0) / N
-assert all(np.array_equal(x, y) for x, y in zip(outs[0], ref)) and all(np.array_equal(x, y) for x, y in zip(outs[1], ref))
-up = sum(src[k].nbytes for k in src) + sum(v.nbytes for v in blk.values())
-print("%s host memory, %d batches of %d pairs: %.2f ms per batch = %.0f GCUPS (%.1f M pairs/s); up %.0f MB (%.1f GB/s if "
-      "transfers alone filled the time), down %.0f MB" % ("pinned" if pinned else "pageable", N, n_pairs, dt * 1e3,
-                                                          n_pairs * 16 * (L + 8) / dt / 1e9, n_pairs / dt / 1e6, up / 1e6,
-                                                          up / dt / 1e9, n_pairs * 16 / 1e6))
+if __name__ == "__main__":
+    W = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
+    N = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+    pinned = (int(sys.argv[3]) if len(sys.argv) > 3 else 1) != 0
+    print("host-to-device copy of 256 MiB from page-locked memory: %.1f GB/s" % link_rate())
+    m = measure(W, N, pinned)
+    assert m["results_equal_across_batches"]
+    print("%s host memory, %d batches of %d pairs: %.2f ms per batch = %.0f GCUPS (%.1f M pairs/s); up %.0f MB (%.1f GB/s if "
+          "transfers alone filled the time), down %.0f MB" % (m["host_memory"], m["batches"], m["pairs_per_batch"],
+                                                              m["ms_per_batch"], m["gcups"], m["pairs_per_s"] / 1e6,
+                                                              m["bytes_up"] / 1e6, m["upload_gbps"], m["bytes_down"] / 1e6))
