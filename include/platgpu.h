@@ -89,6 +89,8 @@ int pg_set_params(pg_ctx *ctx, int gapextend, int nucprior, const char *table, i
  *   "em_kernel"      small | big | multi   EM path of pg_caller_launch
  *   "gl_kernel"      cell | tile           genotype-likelihood kernel of pg_caller_launch
  *   "em_stage_max"   doubles of one window the "big" EM kernel may keep in LDS
+ *   "em_step"        full | sym            the "multi" path's step reads whole matrices or their upper triangle
+ *   "em_step_waves"  1..16 wavefronts per workgroup of the triangle step
  *   "vote_waves"     1..4 wavefronts per workgroup of the anchoring kernel
  *   "align_lds_pad"  bytes of unused LDS per workgroup of the DP kernel (lowers occupancy)
  * The process environment is never consulted.

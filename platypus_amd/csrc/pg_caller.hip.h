@@ -604,6 +604,165 @@ __global__ __launch_bounds__(512) void k_em_step(const WinDesc* __restrict__ win
     }
 }
 
+// The same step from the upper triangle alone: the matrix is symmetric, so every element P_ab (a <= b) is
+// fetched once and used twice, y_b += P_ab f_a and (b > a) y_a += P_ab f_b -- half the bytes of k_em_step, which
+// streams both halves.  A wavefront takes blocks of kSymRows rows and walks each from the diagonal to the right edge
+// in tiles of 64 columns: each lane owns a column (kSymRows independent loads in flight, and the next tile's are
+// issued before this tile's are used), adds the column part in registers and keeps one row-part sum per row of
+// its own; at the end of a row block those are handed to eight lanes per row through an 8 x 64 LDS tile --
+// a transposition, no cross-lane reduction per row beyond three exchange steps.  Every wavefront accumulates
+// into its own copy of y (no atomics: sums are reproducible run to run); the copies are added in wavefront order.
+// Row blocks are dealt back and forth (0..W-1, 2W-1..W, ...): a block near the top has the most tiles.
+// LDS: f [n_pad] | per wavefront: y [n_pad], tile [8][65]; n_pad = n_max rounded up to whole wavefronts.
+constexpr int kSymRows = 8;
+constexpr int kSymTile = 8 * 65;
+
+struct SymTile { int a0, cb; bool ok; };
+
+// the tile after `t` on this wavefront's walk; `round` counts its row blocks
+__device__ __forceinline__ SymTile sym_next(SymTile t, int& round, int wave, int n_wav, int n, int n_cb)
+{
+    ++t.cb;
+    if (t.ok && t.cb < n_cb) return t;
+    ++round;
+    t.a0 = kSymRows * (round * n_wav + ((round & 1) ? n_wav - 1 - wave : wave));
+    t.cb = t.a0 >> 6;
+    t.ok = t.a0 < n;
+    return t;
+}
+
+// No load is conditional (the compiler would wait for all of them before the first use).  Lanes past the
+// matrix edge re-read the last column and lanes left of the diagonal re-read the diagonal -- lines the row
+// fetches anyway -- and rows past the edge read whatever follows (the next matrix, the zeroed slack behind the
+// last one); what they fetch meets a frequency of zero from the padded copy in LDS, or is discarded.
+template <bool DIAG>
+__device__ __forceinline__ void sym_load(double (&p)[kSymRows], const double* __restrict__ P, SymTile t, int n, int lane)
+{
+    const int b = min((t.cb << 6) + lane, n - 1);
+    const double* row = P + (int64_t)t.a0 * n;
+#pragma unroll
+    for (int r = 0; r < kSymRows; ++r) p[r] = row[(int64_t)r * n + (DIAG ? max(b, min(t.a0 + r, n - 1)) : b)];
+}
+
+__device__ __forceinline__ void sym_load_any(double (&p)[kSymRows], const double* __restrict__ P, SymTile t, int n, int lane)
+{
+    if (t.cb == t.a0 >> 6) sym_load<true>(p, P, t, n, lane);
+    else                   sym_load<false>(p, P, t, n, lane);
+}
+
+// One tile's contribution: the column part goes to the wavefront's copy of y, the row part to the lane's sums z.
+// DIAG: the tile holds diagonal elements, and what the lanes left of them fetched is not theirs.
+template <bool DIAG>
+__device__ __forceinline__ void sym_tile(const double (&p)[kSymRows], double (&z)[kSymRows], SymTile t, int lane,
+                                         const double* f, double* yw)
+{
+    const int a0 = t.a0, b = (t.cb << 6) + lane;
+    const double fb = f[b];
+    double yc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < kSymRows; ++r) {
+        const int a = a0 + r;
+        const double v = p[r];
+        yc[r & 3] += (!DIAG || b >= a ? v : 0.0) * f[a];
+        z[r] += (!DIAG || b > a ? v : 0.0) * fb;
+    }
+    yw[b] += (yc[0] + yc[1]) + (yc[2] + yc[3]);
+}
+
+// End of a row block: the lanes' row-part sums, added over the wavefront, go to y; z is cleared.
+__device__ __forceinline__ void sym_rows(double (&z)[kSymRows], int a0, int lane, double* yw, double* tile)
+{
+    const int q = lane & 7, rr = lane >> 3;
+#pragma unroll
+    for (int half = 0; half < kSymRows / 8; ++half) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { tile[r * 65 + lane] = z[8 * half + r]; z[8 * half + r] = 0.0; }
+        double s0 = 0.0, s1 = 0.0;                       // LDS operations of one wavefront complete in order
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) { s0 += tile[rr * 65 + 8 * q + j]; s1 += tile[rr * 65 + 8 * q + j + 1]; }
+        double srow = s0 + s1;
+        srow += dpp_f64<0xB1>(srow);                     // quad_perm [1,0,3,2]
+        srow += dpp_f64<0x4E>(srow);                     // quad_perm [2,3,0,1]
+        srow += dpp_f64<0x141>(srow);                    // row_half_mirror: the other quad of the eight
+        if (q == 0) yw[a0 + 8 * half + rr] += srow;
+    }
+}
+
+__device__ __forceinline__ void sym_step(const double (&p)[kSymRows], double (&z)[kSymRows], SymTile t, bool last,
+                                         int lane, const double* f, double* yw, double* tile)
+{
+    if (t.cb == t.a0 >> 6) sym_tile<true>(p, z, t, lane, f, yw);
+    else                   sym_tile<false>(p, z, t, lane, f, yw);
+    if (last) sym_rows(z, t.a0, lane, yw, tile);
+}
+
+// LDS doubles per vector: the columns rounded up to whole wavefronts (the rows, to whole row blocks, are fewer)
+__host__ __device__ inline int sym_pad(int n_max) { return ((n_max + 63) & ~63); }
+// doubles a step may read past the end of the last matrix
+__host__ __device__ inline int64_t sym_slack(int n_max) { return (int64_t)kSymRows * (n_max + 64); }
+
+__global__ __launch_bounds__(1024) void k_em_step_sym(const WinDesc* __restrict__ wins, const int32_t* __restrict__ ioff,
+                                                      const double* __restrict__ full, EmState S, int n_max)
+{
+    extern __shared__ double em_lds[];
+    __shared__ double s_part[16];
+    const int w = blockIdx.x;
+    if (S.done[w]) return;
+    const WinDesc W = wins[w];
+    const int i = blockIdx.y;
+    if (i >= W.n_ind) return;
+    const int32_t* io = ioff + W.ioff_base;
+    if (io[i + 1] == io[i]) return;                                          // cpopulation.pyx:834-835
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);               // the tile walk stays in scalar registers
+    const int n_thr = blockDim.x, n_wav = n_thr >> 6;
+    const int n = W.n_hap, n_pad = sym_pad(n_max);
+    double* f = em_lds;
+    double* yw = em_lds + n_pad + (size_t)wave * n_pad;
+    double* tile = em_lds + (size_t)(1 + n_wav) * n_pad + (size_t)wave * kSymTile;
+    const double* P = full + W.full_base + (int64_t)i * n * n;
+    const int n_cb = (n + 63) >> 6;
+    int round = -1;
+    SymTile t0 = sym_next(SymTile{0, 0, false}, round, wave, n_wav, n, n_cb), t1;
+    double p0[kSymRows], p1[kSymRows], z[kSymRows];
+#pragma unroll
+    for (int r = 0; r < kSymRows; ++r) z[r] = 0.0;
+    if (t0.ok) sym_load_any(p0, P, t0, n, lane);         // in flight while the frequencies are staged
+    const double* f_glob = S.f + W.hap_base;
+    for (int k = tid; k < n_pad; k += n_thr) f[k] = k < n ? f_glob[k] : 0.0;
+    for (int k = lane; k < n_pad; k += 64) yw[k] = 0.0;
+    __syncthreads();
+    // two register sets take turns: the next tile's loads are issued before this tile's values are used
+    while (t0.ok) {
+        t1 = sym_next(t0, round, wave, n_wav, n, n_cb);
+        sym_load_any(p1, P, t1.ok ? t1 : t0, n, lane);
+        sym_step(p0, z, t0, !(t1.ok && t1.a0 == t0.a0), lane, f, yw, tile);
+        if (!t1.ok) break;
+        t0 = sym_next(t1, round, wave, n_wav, n, n_cb);
+        sym_load_any(p0, P, t0.ok ? t0 : t1, n, lane);
+        sym_step(p1, z, t1, !(t0.ok && t0.a0 == t1.a0), lane, f, yw, tile);
+    }
+    __syncthreads();
+    double part = 0.0;
+    double* y0 = em_lds + n_pad;
+    for (int k = tid; k < n; k += n_thr) {
+        double y = y0[k];
+        for (int v = 1; v < n_wav; ++v) y += y0[(size_t)v * n_pad + k];      // wavefront order
+        y0[k] = y;                                    // this thread is the only reader of column k
+        part += f[k] * y;
+    }
+    part = wave_sum(part);
+    if (lane == 0) s_part[wave] = part;
+    __syncthreads();
+    double s = s_part[0];                                                    // csrSum, cpopulation.pyx:849
+    for (int v = 1; v < n_wav; ++v) s += s_part[v];
+    double* sh = S.share + S.share_base[w] + (int64_t)i * n;
+    for (int k = tid; k < n; k += n_thr) {
+        const double tt = 2.0 * f[k] * y0[k];
+        sh[k] = s > 0.0 ? tt / s : tt;                                       // cpopulation.pyx:852-854
+    }
+}
+
 // Genotype calls (cpopulation.pyx:773-797) from the last iteration's old frequencies, in the shape of
 // k_em_step: one workgroup per (window, individual), matrix rows split between its wavefronts, for the
 // product that gives csrSum and again for the scan of the upper triangle; the wavefronts' best

@@ -107,6 +107,8 @@ struct pg_ctx {
     int gl_kernel = -1;                  // "gl_kernel": 0 cell, 1 tile
     int em_kernel = -1;                  // "em_kernel": 0 small, 1 big, 2 multi
     int64_t em_stage_max = 16384;        // "em_stage_max": doubles of a window the big EM kernel may keep in LDS
+    int em_step = -1;                    // "em_step": 0 full matrix, 1 upper triangle (launch-pair EM path)
+    int em_step_waves = 0;               // "em_step_waves": wavefronts per workgroup of the triangle step (1..8)
     int32_t* h_status = nullptr;         // pinned: status words of the last pair-list preparation
     DevBuf<double> d_exp_score, d_exp_mapq;
 
@@ -489,6 +491,11 @@ int pg_set_option(pg_ctx* c, const char* name, const char* value) {
         else return fail(c, PG_ERR_INVALID, "gl_kernel: cell, tile or default");
     } else if (n == "em_stage_max") {
         c->em_stage_max = dflt ? 16384 : std::max<int64_t>(0, std::atoll(value));
+    } else if (n == "em_step") {
+        if (dflt) c->em_step = -1; else if (v == "full") c->em_step = 0; else if (v == "sym") c->em_step = 1;
+        else return fail(c, PG_ERR_INVALID, "em_step: full, sym or default");
+    } else if (n == "em_step_waves") {
+        c->em_step_waves = dflt ? 0 : std::max(1, std::min(16, std::atoi(value)));
     } else if (n == "vote_waves") {
         c->vote_waves = dflt ? 0 : std::max(1, std::min(4, std::atoi(value)));
     } else if (n == "align_lds_pad") {
@@ -936,7 +943,10 @@ int pg_windows_upload(pg_ctx* c, int nw, const int32_t* n_haps, const int32_t* n
     }
     PG_HIP(c, hipSetDevice(c->device));
     PG_HIP(c, c->d_wins.reserve((size_t)nw + 1)); PG_HIP(c, c->d_ioff.reserve((size_t)ioff + 1));
-    PG_HIP(c, c->d_cells.reserve((size_t)cells + 1)); PG_HIP(c, c->d_full.reserve((size_t)full + 1));
+    PG_HIP(c, c->d_cells.reserve((size_t)cells + 1));
+    // the triangle step reads up to sym_slack doubles past the last matrix, and they must be finite
+    PG_HIP(c, c->d_full.reserve((size_t)(full + pg::sym_slack(max_h)) + 1));
+    PG_HIP(c, hipMemsetAsync(c->d_full.p + full, 0, sizeof(double) * (size_t)pg::sym_slack(max_h), c->stream));
     PG_HIP(c, c->d_freq.reserve((size_t)haps + 1)); PG_HIP(c, c->d_em_iters.reserve((size_t)nw + 1));
     PG_HIP(c, c->d_em_change.reserve((size_t)nw + 1)); PG_HIP(c, c->d_best_gen.reserve((size_t)inds + 1));
     PG_HIP(c, c->d_best_val.reserve((size_t)inds + 1));
@@ -1038,6 +1048,19 @@ int pg_caller_launch(pg_ctx* c, int max_iters) {
         const int step_threads = n_max <= 64 ? 64 : (n_max <= 128 ? 256 : 512);
         const size_t lds_step = (size_t)(1 + step_threads / 64) * n_max * sizeof(double);
         PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_em_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step));
+        // matrices wider than a wavefront are stepped from their upper triangle alone (half the bytes)
+        const bool sym = c->em_step >= 0 ? c->em_step == 1 : n_max > 64;
+        // sixteen wavefronts per (window, individual) where LDS allows: the fewer tiles a wavefront walks one after
+        // the other, the shorter the last workgroups of a launch run alone
+        auto sym_lds = [&](int waves) { return ((size_t)(1 + waves) * pg::sym_pad(n_max) + (size_t)waves * pg::kSymTile) * sizeof(double); };
+        int sym_waves = c->em_step_waves > 0 ? c->em_step_waves : 8;
+        while (sym_waves > 1 && sym_lds(sym_waves) > 160 * 1024) sym_waves >>= 1;
+        const int sym_threads = 64 * sym_waves;
+        const size_t lds_sym = sym_lds(sym_waves);
+        if (sym) {
+            if (lds_sym > 160 * 1024) return fail(c, PG_ERR_UNSUPPORTED, "EM step of %d haplotypes needs %zu bytes of LDS", n_max, lds_sym);
+            PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_em_step_sym), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sym));
+        }
         // Blocks of eight iterations.  After every block the number of windows still running is copied to
         // pinned host memory; the host reads the answer of block b only after it has queued block b + 1, so the
         // device never waits for the host (a converged window's workgroups return at once: the one block that
@@ -1052,7 +1075,10 @@ int pg_caller_launch(pg_ctx* c, int max_iters) {
                 if (c->h_active[b & 1] <= 0) break;
             }
             for (int it = 8 * b; it < std::min(max_iters, 8 * b + 8); ++it) {
-                hipLaunchKernelGGL(pg::k_em_step, dim3(c->n_windows, c->max_win_inds), dim3(step_threads), lds_step, c->stream, c->d_wins.p, c->d_ioff.p, c->d_full.p, S, n_max);
+                if (sym)
+                    hipLaunchKernelGGL(pg::k_em_step_sym, dim3(c->n_windows, c->max_win_inds), dim3(sym_threads), lds_sym, c->stream, c->d_wins.p, c->d_ioff.p, c->d_full.p, S, n_max);
+                else
+                    hipLaunchKernelGGL(pg::k_em_step, dim3(c->n_windows, c->max_win_inds), dim3(step_threads), lds_step, c->stream, c->d_wins.p, c->d_ioff.p, c->d_full.p, S, n_max);
                 hipLaunchKernelGGL(pg::k_em_update, dim3(c->n_windows), dim3(256), lds_update, c->stream, c->d_wins.p, c->d_ioff.p, S, max_iters);
             }
             PG_HIP(c, hipMemcpyAsync(&c->h_active[b & 1], S.active, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
