@@ -286,6 +286,15 @@ def main():
         caller = {"windows": n_windows, "haplotypes": H, "individuals": n_inds,
                   "setup_ms": ctx.kernel_ms(native.PG_K_CALLER_SETUP), "em_ms": ctx.kernel_ms(native.PG_K_CALLER_EM),
                   "em_iterations_mean": float(res["iters"].mean()), "em_iterations_max": int(res["iters"].max())}
+        if args.workload == "joint":
+            # The EM stage streams every individual's genotype-likelihood matrix once per iteration of its window:
+            # algorithmic bytes = iterations x individuals x H (H + 1) / 2 doubles (the matrix is symmetric), over
+            # the whole stage's time (steps, updates and the final calls).
+            em_bytes = float(res["iters"].sum()) * n_inds * (H * (H + 1) // 2) * 8.0
+            em_s = caller["em_ms"] * 1e-3
+            caller["roofline"] = {"bound": "hbm", "kernel": "k_em_step_sym", "achieved": em_bytes / em_s / 1e9, "peak": 8000.0,
+                                  "unit": "GB/s", "frac": em_bytes / em_s / 8e12, "algorithmic_bytes": em_bytes,
+                                  "traffic": None}
     except native.PlatGpuError as e:                       # reported, never hidden
         caller = {"error": str(e)}
 

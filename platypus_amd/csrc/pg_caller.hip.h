@@ -529,6 +529,7 @@ struct EmState {
     double* change;     // per window
     int32_t* done;      // per window
     int32_t* active;    // one counter
+    int32_t* arrived;   // per window: workgroups of the running step that have stored their share
     const int64_t* share_base;   // per window: offset into share
 };
 
@@ -543,7 +544,7 @@ __global__ __launch_bounds__(256) void k_em_init(const WinDesc* __restrict__ win
     if (threadIdx.x == 0) {
         double eps = 1.0 / (W.n_ind * 2 * 2);
         eps = eps < 1e-3 ? eps : 1e-3;
-        S.iters[w] = 0; S.change[w] = eps + 1; S.done[w] = 0;                // cpopulation.pyx:751-752
+        S.iters[w] = 0; S.change[w] = eps + 1; S.done[w] = 0; S.arrived[w] = 0;   // cpopulation.pyx:751-752
         if (w == 0) *S.active = n_win;
     }
 }
@@ -601,6 +602,78 @@ __global__ __launch_bounds__(512) void k_em_step(const WinDesc* __restrict__ win
     for (int k = tid; k < n; k += n_thr) {
         const double t = 2.0 * f[k] * y0[k];
         sh[k] = s > 0.0 ? t / s : t;                                         // cpopulation.pyx:852-854
+    }
+}
+
+// Shares written and read within ONE launch (by different workgroups, possibly on different dies of the chip)
+// go past the caches that are not kept coherent between dies: device-scope stores and loads, so that no
+// workgroup has to write back or invalidate a whole cache to publish or to see them.
+__device__ __forceinline__ void share_store(double* p, double v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool SAME_LAUNCH>
+__device__ __forceinline__ double share_load(const double* p) {
+    if (SAME_LAUNCH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+
+// New frequencies of one window from the individuals' shares (added in individual order), largest change,
+// convergence flag: the work of one workgroup of n_thr threads (at most 16 wavefronts).  s_has: one byte per
+// individual in LDS.
+template <bool SAME_LAUNCH>
+__device__ __forceinline__ void em_update_window(const WinDesc& W, const int32_t* __restrict__ io, EmState S, int w,
+                                                 int max_iters, int tid, int n_thr, unsigned char* s_has,
+                                                 double* s_red, int* s_count)
+{
+    const int n = W.n_hap, n_wav = n_thr >> 6;
+    // which individuals have reads: read once by the whole workgroup (every thread reading all of them
+    // was most of this kernel's time)
+    int mine = 0;
+    for (int i = tid; i < W.n_ind; i += n_thr) {
+        const int h = io[i + 1] != io[i];
+        s_has[i] = (unsigned char)h;
+        mine += h;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+    if ((tid & 63) == 0) s_count[tid >> 6] = mine;
+    __syncthreads();
+    int n_with_data = 0;
+    for (int v = 0; v < n_wav; ++v) n_with_data += s_count[v];
+    const double* sh = S.share + S.share_base[w];
+    double ch = 0.0;
+    for (int k = tid; k < n; k += n_thr) {
+        double t = 0.0;
+        // eight shares are fetched before the first is added (the compiler keeps loads where they
+        // are written, and fifty dependent load-add steps are fifty memory latencies); the
+        // additions stay in individual order
+        for (int i0 = 0; i0 < W.n_ind; i0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = i0 + j < W.n_ind ? share_load<SAME_LAUNCH>(sh + (int64_t)(i0 + j) * n + k) : 0.0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (i0 + j < W.n_ind && s_has[i0 + j]) t += v[j];             // cpopulation.pyx:869-880, individual order
+        }
+        const double old = S.f[W.hap_base + k], nf = t / (2 * n_with_data);  // :883
+        S.f_prev[W.hap_base + k] = old;
+        S.f[W.hap_base + k] = nf;
+        ch = fmax(ch, fabs(old - nf));                                       // :885-888
+    }
+    ch = wave_max(ch);
+    if ((tid & 63) == 0) s_red[tid >> 6] = ch;
+    __syncthreads();
+    if (tid == 0) {
+        for (int v = 1; v < n_wav; ++v) ch = fmax(ch, s_red[v]);
+        double eps = 1.0 / (W.n_ind * 2 * 2);
+        eps = eps < 1e-3 ? eps : 1e-3;
+        const int it = S.iters[w] + 1;
+        S.iters[w] = it;
+        S.change[w] = ch;
+        if (!(ch > eps && it < max_iters)) {                                 // :766
+            S.done[w] = 1;
+            atomicSub(S.active, 1);
+        }
     }
 }
 
@@ -701,18 +774,10 @@ __host__ __device__ inline int sym_pad(int n_max) { return ((n_max + 63) & ~63);
 // doubles a step may read past the end of the last matrix
 __host__ __device__ inline int64_t sym_slack(int n_max) { return (int64_t)kSymRows * (n_max + 64); }
 
-__global__ __launch_bounds__(1024) void k_em_step_sym(const WinDesc* __restrict__ wins, const int32_t* __restrict__ ioff,
-                                                      const double* __restrict__ full, EmState S, int n_max)
+// One individual's share of every haplotype's total, from the upper triangle of its matrix.
+__device__ __forceinline__ void sym_share(const WinDesc& W, int i, const double* __restrict__ full, EmState S, int w,
+                                          int n_max, double* em_lds, double* s_part)
 {
-    extern __shared__ double em_lds[];
-    __shared__ double s_part[16];
-    const int w = blockIdx.x;
-    if (S.done[w]) return;
-    const WinDesc W = wins[w];
-    const int i = blockIdx.y;
-    if (i >= W.n_ind) return;
-    const int32_t* io = ioff + W.ioff_base;
-    if (io[i + 1] == io[i]) return;                                          // cpopulation.pyx:834-835
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);               // the tile walk stays in scalar registers
     const int n_thr = blockDim.x, n_wav = n_thr >> 6;
@@ -759,8 +824,42 @@ __global__ __launch_bounds__(1024) void k_em_step_sym(const WinDesc* __restrict_
     double* sh = S.share + S.share_base[w] + (int64_t)i * n;
     for (int k = tid; k < n; k += n_thr) {
         const double tt = 2.0 * f[k] * y0[k];
-        sh[k] = s > 0.0 ? tt / s : tt;                                       // cpopulation.pyx:852-854
+        share_store(sh + k, s > 0.0 ? tt / s : tt);                          // cpopulation.pyx:852-854
     }
+}
+
+// grid (window, individual).  Dynamic LDS: the layout above, and at least one byte per individual of a window.
+__global__ __launch_bounds__(1024) void k_em_step_sym(const WinDesc* __restrict__ wins, const int32_t* __restrict__ ioff,
+                                                      const double* __restrict__ full, EmState S, int n_max,
+                                                      int max_iters)
+{
+    extern __shared__ double em_lds[];
+    __shared__ double s_part[16];
+    __shared__ int s_count[16];
+    __shared__ int s_last;
+    const int w = blockIdx.x;
+    if (S.done[w]) return;
+    const WinDesc W = wins[w];
+    const int i = blockIdx.y;
+    if (i >= W.n_ind) return;
+    const int32_t* io = ioff + W.ioff_base;
+    const int tid = threadIdx.x;
+    if (io[i + 1] != io[i])                                                  // cpopulation.pyx:834-835
+        sym_share(W, i, full, S, w, n_max, em_lds, s_part);
+    // The window's last workgroup to get here does the window's update: every workgroup's shares have reached
+    // device scope before it counts itself (its wavefronts wait for their stores, then the barrier), the
+    // frequencies that are replaced have been read by all of them, and nothing reads the new ones before the
+    // next launch.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (tid == 0) {
+        const int last = __hip_atomic_fetch_add(&S.arrived[w], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == W.n_ind - 1;
+        if (last) S.arrived[w] = 0;
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    em_update_window<true>(W, io, S, w, max_iters, tid, blockDim.x, reinterpret_cast<unsigned char*>(em_lds), s_part, s_count);
 }
 
 // Genotype calls (cpopulation.pyx:773-797) from the last iteration's old frequencies, in the shape of
@@ -854,56 +953,7 @@ __global__ __launch_bounds__(256) void k_em_update(const WinDesc* __restrict__ w
     const int w = blockIdx.x;
     if (S.done[w]) return;
     const WinDesc W = wins[w];
-    const int tid = threadIdx.x, n = W.n_hap;
-    const int32_t* io = ioff + W.ioff_base;
-    // which individuals have reads: read once by the whole workgroup (every thread reading all of them
-    // was most of this kernel's time)
-    int mine = 0;
-    for (int i = tid; i < W.n_ind; i += 256) {
-        const int h = io[i + 1] != io[i];
-        s_has[i] = (unsigned char)h;
-        mine += h;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
-    if ((tid & 63) == 0) s_count[tid >> 6] = mine;
-    __syncthreads();
-    const int n_with_data = s_count[0] + s_count[1] + s_count[2] + s_count[3];
-    const double* sh = S.share + S.share_base[w];
-    double ch = 0.0;
-    for (int k = tid; k < n; k += 256) {
-        double t = 0.0;
-        // eight shares are fetched before the first is added (the compiler keeps loads where they
-        // are written, and fifty dependent load-add steps are fifty memory latencies); the
-        // additions stay in individual order
-        for (int i0 = 0; i0 < W.n_ind; i0 += 8) {
-            double v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = i0 + j < W.n_ind ? sh[(int64_t)(i0 + j) * n + k] : 0.0;
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (i0 + j < W.n_ind && s_has[i0 + j]) t += v[j];             // cpopulation.pyx:869-880, individual order
-        }
-        const double old = S.f[W.hap_base + k], nf = t / (2 * n_with_data);  // :883
-        S.f_prev[W.hap_base + k] = old;
-        S.f[W.hap_base + k] = nf;
-        ch = fmax(ch, fabs(old - nf));                                       // :885-888
-    }
-    ch = wave_max(ch);
-    if ((tid & 63) == 0) s_red[tid >> 6] = ch;
-    __syncthreads();
-    if (tid == 0) {
-        ch = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
-        double eps = 1.0 / (W.n_ind * 2 * 2);
-        eps = eps < 1e-3 ? eps : 1e-3;
-        const int it = S.iters[w] + 1;
-        S.iters[w] = it;
-        S.change[w] = ch;
-        if (!(ch > eps && it < max_iters)) {                                 // :766
-            S.done[w] = 1;
-            atomicSub(S.active, 1);
-        }
-    }
+    em_update_window<false>(W, ioff + W.ioff_base, S, w, max_iters, threadIdx.x, 256, s_has, s_red, s_count);
 }
 
 // ---------------------------------------------------------------------------

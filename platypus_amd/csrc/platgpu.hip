@@ -1036,10 +1036,10 @@ int pg_caller_launch(pg_ctx* c, int max_iters) {
     } else {
         PG_HIP(c, c->d_fprev.reserve((size_t)c->win_haps_total + 1));
         PG_HIP(c, c->d_share.reserve((size_t)c->win_share + 1));
-        PG_HIP(c, c->d_em_done.reserve((size_t)c->n_windows + 1));     // [n_windows] = windows still running
+        PG_HIP(c, c->d_em_done.reserve(2 * (size_t)c->n_windows + 1)); // [n_windows] = windows still running, then one arrival counter per window
         pg::EmState S;
         S.f = c->d_freq.p; S.f_prev = c->d_fprev.p; S.share = c->d_share.p; S.iters = c->d_em_iters.p;
-        S.change = c->d_em_change.p; S.done = c->d_em_done.p; S.active = c->d_em_done.p + c->n_windows;
+        S.change = c->d_em_change.p; S.done = c->d_em_done.p; S.active = c->d_em_done.p + c->n_windows; S.arrived = S.active + 1;
         S.share_base = c->d_share_base.p;
         hipLaunchKernelGGL(pg::k_em_init, dim3(c->n_windows), dim3(256), 0, c->stream, c->d_wins.p, c->n_windows, S);
         int32_t active = c->n_windows;
@@ -1056,7 +1056,7 @@ int pg_caller_launch(pg_ctx* c, int max_iters) {
         int sym_waves = c->em_step_waves > 0 ? c->em_step_waves : 8;
         while (sym_waves > 1 && sym_lds(sym_waves) > 160 * 1024) sym_waves >>= 1;
         const int sym_threads = 64 * sym_waves;
-        const size_t lds_sym = sym_lds(sym_waves);
+        const size_t lds_sym = std::max(sym_lds(sym_waves), (size_t)((c->max_win_inds + 15) & ~15));
         if (sym) {
             if (lds_sym > 160 * 1024) return fail(c, PG_ERR_UNSUPPORTED, "EM step of %d haplotypes needs %zu bytes of LDS", n_max, lds_sym);
             PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_em_step_sym), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sym));
@@ -1075,11 +1075,12 @@ int pg_caller_launch(pg_ctx* c, int max_iters) {
                 if (c->h_active[b & 1] <= 0) break;
             }
             for (int it = 8 * b; it < std::min(max_iters, 8 * b + 8); ++it) {
-                if (sym)
-                    hipLaunchKernelGGL(pg::k_em_step_sym, dim3(c->n_windows, c->max_win_inds), dim3(sym_threads), lds_sym, c->stream, c->d_wins.p, c->d_ioff.p, c->d_full.p, S, n_max);
-                else
+                if (sym) {            // the last workgroup of a window to finish does the window's update
+                    hipLaunchKernelGGL(pg::k_em_step_sym, dim3(c->n_windows, c->max_win_inds), dim3(sym_threads), lds_sym, c->stream, c->d_wins.p, c->d_ioff.p, c->d_full.p, S, n_max, max_iters);
+                } else {
                     hipLaunchKernelGGL(pg::k_em_step, dim3(c->n_windows, c->max_win_inds), dim3(step_threads), lds_step, c->stream, c->d_wins.p, c->d_ioff.p, c->d_full.p, S, n_max);
-                hipLaunchKernelGGL(pg::k_em_update, dim3(c->n_windows), dim3(256), lds_update, c->stream, c->d_wins.p, c->d_ioff.p, S, max_iters);
+                    hipLaunchKernelGGL(pg::k_em_update, dim3(c->n_windows), dim3(256), lds_update, c->stream, c->d_wins.p, c->d_ioff.p, S, max_iters);
+                }
             }
             PG_HIP(c, hipMemcpyAsync(&c->h_active[b & 1], S.active, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
             PG_HIP(c, hipEventRecord(c->ev_block[b & 1], c->stream));

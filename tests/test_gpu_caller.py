@@ -172,6 +172,18 @@ def test_em_kernel_paths_against_checker(which):
     run_case(n_windows=7, H=5, R=40, n_ind=3, seed=42, options=opt)
 
 
+@pytest.mark.parametrize("step", ["full", "sym"])
+def test_em_step_kernels_against_checker(step):
+    """the launch-pair path's step from whole matrices and from their upper triangle (whose last workgroup per
+    window does the update), forced: matrices narrower than a wavefront, of one and a bit and of several
+    wavefronts' width, an individual without reads, one to sixteen wavefronts per workgroup"""
+    opt = [("em_kernel", "multi"), ("em_step", step)]
+    run_case(n_windows=5, H=40, R=120, n_ind=9, seed=44, indel_frac=0.2, empty=2, options=opt)
+    run_case(n_windows=3, H=65, R=90, n_ind=5, seed=45, empty=0, read_len=40, hap_len=200, options=opt)
+    run_case(n_windows=2, H=130, R=80, n_ind=3, seed=46, read_len=40, hap_len=200, options=opt + [("em_step_waves", "16")])
+    run_case(n_windows=4, H=9, R=40, n_ind=4, seed=47, empty=3, options=opt + [("em_step_waves", "1")])
+
+
 def test_em_iteration_cap():
     """max_iters is honoured by every path (the reference's default is 100, cpopulation.pyx:741)"""
     from platypus_amd import native
