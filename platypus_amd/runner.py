@@ -63,6 +63,8 @@ def call_chunks(chunks, args, tmpdir):
     units = [(ch, s, min(s + args.bufferSize, ch[2])) for ch in chunks for s in range(ch[1], ch[2], args.bufferSize)]
 
     spent = {"fetch": 0.0, "buffers": 0.0, "candidates": 0.0, "wait": 0.0, "call": 0.0, "write": 0.0}
+    phases = {}                                           # seconds per phase of callRegion, summed (timing report only)
+    timed = bool(os.environ.get("PLATYPUS_AMD_TIMINGS"))
 
     local = threading.local()
     opened = []
@@ -125,7 +127,12 @@ def call_chunks(chunks, args, tmpdir):
                 continue
             t0 = time.perf_counter()
             try:
-                calls = pipeline.callRegion(chrom.encode(), s, e, bufs, fa, opts, variants=cands)
+                stats = {} if timed else None
+                calls = pipeline.callRegion(chrom.encode(), s, e, bufs, fa, opts, variants=cands, stats=stats)
+                if timed:
+                    for k, v in stats.items():
+                        if k.startswith("t_") or k in ("pack", "upload", "device", "unpack"):
+                            phases[k] = phases.get(k, 0.0) + v
             except Exception as err:                          # one stretch is lost, the run goes on (variantcaller.pyx:189-191)
                 logging.getLogger("Log").error("No calls for %s:%d-%d: %s: %s", chrom, s, e, type(err).__name__, err)
                 calls = []
@@ -139,11 +146,12 @@ def call_chunks(chunks, args, tmpdir):
         out.close()
     for r in readers + opened:
         r.close()
-    if os.environ.get("PLATYPUS_AMD_TIMINGS"):             # where a worker's time went (helper thread: fetch, buffers)
+    if timed:                                             # where a worker's time went (helper thread: fetch, buffers)
         sys.stderr.write("worker %d: %d calls; helper threads: fetch %.2f s, buffers %.2f s, candidates %.2f s; main thread: "
-                         "waiting %.2f s, calling %.2f s, writing %.2f s\n" % (
+                         "waiting %.2f s, calling %.2f s, writing %.2f s; phases of calling: %s\n" % (
                              os.getpid(), n_calls, spent["fetch"], spent["buffers"], spent["candidates"], spent["wait"],
-                             spent["call"], spent["write"]))
+                             spent["call"], spent["write"],
+                             ", ".join("%s %.2f" % (k, v) for k, v in sorted(phases.items()))))
     return n_calls
 
 
