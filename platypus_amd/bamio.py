@@ -169,6 +169,40 @@ def _concat(parts):
     return out
 
 
+def drop_before(arrays, start):
+    """the packed records (in position order) whose position is >= start"""
+    i0 = int(np.searchsorted(arrays["pos"], start, side="left"))
+    if i0 == 0:
+        return arrays
+    out = {}
+    s0, c0 = int(arrays["off"][i0]), int(arrays["cigarOff"][i0])
+    for k in ("pos", "mapq", "flag", "insertSize", "matePos"):
+        out[k] = arrays[k][i0:]
+    out["seq"], out["qual"], out["cigar"] = arrays["seq"][s0:], arrays["qual"][s0:], arrays["cigar"][c0:]
+    out["off"], out["cigarOff"] = arrays["off"][i0:] - s0, arrays["cigarOff"][i0:] - c0
+    return out
+
+
+def fetch_split(path, chrom, start, end, parts):
+    """BamReader.fetch(chrom, start, end) with the stretch cut into `parts` pieces that are read, inflated and decoded
+    side by side (every piece on a thread and a file handle of its own; a piece after the first keeps the records
+    that start inside it, so every record is returned once, in position order)."""
+    from concurrent.futures import ThreadPoolExecutor
+    edges = [start + (end - start) * k // parts for k in range(parts + 1)]
+
+    def piece(k):
+        r = BamReader(path)
+        try:
+            a = r.fetch(chrom, edges[k], edges[k + 1])
+        finally:
+            r.close()
+        return a if k == 0 else drop_before(a, edges[k])
+
+    with ThreadPoolExecutor(parts) as pool:
+        got = [a for a in pool.map(piece, range(parts)) if len(a["pos"])]
+    return _concat(got)
+
+
 def _read_linear_index(path):
     with open(path, "rb") as f:
         d = f.read()

@@ -436,14 +436,21 @@ def callRegion(chrom, start, end, readBuffers, refFile, options=None, variants=N
 
     # ---- pass 3: consume -------------------------------------------------------------------------------
     items = []
+    hapVars = []                                                      # per window: every haplotype's variant tuple, fetched once
     for k, i in enumerate(order):
         pop = pops[k]
+        hv = [hap.variantsPy() for hap in pop.haplotypes]
+        hapVars.append(hv)
+        calledHaps = set()
+        for g in pop.genotypeCalls:
+            if g is not None:
+                calledHaps.add(id(g.haplotypes[0]))
+                calledHaps.add(id(g.haplotypes[1]))
         byVar = {}
         for h, hap in enumerate(pop.haplotypes):
-            called = any(g is not None and (hap is g.haplotypes[0] or hap is g.haplotypes[1]) for g in pop.genotypeCalls)
-            if not called:                                            # cpopulation.pyx:497-504
+            if id(hap) not in calledHaps:                             # cpopulation.pyx:497-504
                 continue
-            for v in hap.variantsPy():
+            for v in hv[h]:
                 byVar[v] = True
         for v in byVar:
             items.append((k, v))
@@ -452,35 +459,47 @@ def callRegion(chrom, start, end, readBuffers, refFile, options=None, variants=N
     for (k, v), p in zip(items, posts):
         perWin.setdefault(k, []).append((v, p))
     calls, site_items, site_calls = [], [], []
+    minPosterior = options.minPosterior
     for k, i in enumerate(order):
+        mine = perWin.get(k)
+        if not mine:
+            continue
         pop = pops[k]
         byPos = {}
-        for v, p in perWin.get(k, []):
+        for v, p in mine:
             pp = "%.0f" % (-10.0 * math.log10(max(1e-20, 1.0 - p)))  # cpopulation.pyx:249
-            if float(pp) >= options.minPosterior:                     # variantcaller.pyx:304
+            if float(pp) >= minPosterior:                             # variantcaller.pyx:304
                 byPos.setdefault(v.refPos, []).append((v, p, pp))
         if not byPos:                                                 # nothing of this window is written: no statistics needed
             continue
         freqs = pop.frequenciesPy()
+        hv = hapVars[k]
+        haplotypes = pop.haplotypes
         minQuals, fwdWeight, stats_list = [], [0.0], []
-        all_vars = {}
-        for hap in pop.haplotypes:                                    # INFO and FILTER cover every haplotype's variants
-            for v in hap.variantsPy():
-                all_vars[v] = v
-        for v in sorted(all_vars, key=lambda v: v._key()):
-            fr = sum(f for f, hap in zip(freqs, pop.haplotypes) if v in hap.variantsPy())
-            stats_list.append((v, siteStatistics(batch, k, v, fr, refFile, options, minQuals, fwdWeight)))
+        # frequency of a variant: the frequencies of the haplotypes that carry it, added in haplotype order
+        # (INFO and FILTER cover every haplotype's variants)
+        freqOf = {}
+        for f, vs in zip(freqs, hv):
+            for v in vs:
+                freqOf[v] = freqOf.get(v, 0) + f
+        for v in sorted(freqOf, key=lambda v: v._key()):
+            stats_list.append((v, siteStatistics(batch, k, v, freqOf[v], refFile, options, minQuals, fwdWeight)))
         win_flags = windowFilters(stats_list, options)
         stats_of = {v: st for v, st in stats_list}
         last_var = stats_list[-1][0] if stats_list else None
+        win_filters = sorted(set(win_flags))
+        readCounts = batch.readCounts(k)
+        idxOf = {id(hap): h for h, hap in enumerate(haplotypes)}
         for pos in sorted(byPos):
-            entries = sorted(byPos[pos], key=lambda t: t[0]._key())
+            entries = byPos[pos]
+            if len(entries) > 1:
+                entries = sorted(entries, key=lambda t: t[0]._key())
             vs = [e[0] for e in entries]
             c = Call()
             c.chrom, c.pos, c.variants = chrom, pos, vs
             c.posteriors = [e[1] for e in entries]
             c.PP = [e[2] for e in entries]
-            c.FR = ["%1.4f" % sum(f for f, hap in zip(freqs, pop.haplotypes) if v in hap.variantsPy()) for v in vs]
+            c.FR = ["%1.4f" % freqOf[v] for v in vs]
             c.TR = [v.nSupportingReads for v in vs]
             c.NF = [v.nFwdReads for v in vs]
             c.NR = [v.nRevReads for v in vs]
@@ -488,7 +507,7 @@ def callRegion(chrom, start, end, readBuffers, refFile, options=None, variants=N
             c.TC, c.TCR, c.TCF = st["TC"], st["TCR"], st["TCF"]
             c.HP, c.SC, c.RMP, c.MMLQ = st["HP"], st["SC"], st["RMP"], st["MMLQ"]
             c.FPV, c.RPV, c.ABPV = st["FPV"], st["RPV"], st["ABPV"]
-            c.filters = sorted(set(win_flags)) if any(v == last_var for v in vs) else []
+            c.filters = win_filters if any(v == last_var for v in vs) else []
             c.qual = max(int(pp) for pp in c.PP)
             c.GT, c.GQ, c.GL, c.nReads = [], [], [], []
             for ind, g in enumerate(pop.genotypeCalls):
@@ -496,23 +515,25 @@ def callRegion(chrom, start, end, readBuffers, refFile, options=None, variants=N
                     c.GT.append("./."); c.GQ.append(-1); c.GL.append([-1, -1, -1]); c.nReads.append(0)
                     continue
                 a = b = 0
+                va = hv[idxOf[id(g.haplotypes[0])]]
+                vb = hv[idxOf[id(g.haplotypes[1])]]
                 for vi, v in enumerate(vs):
-                    if v in g.haplotypes[0].variantsPy():
+                    if v in va:
                         a = vi + 1
-                    if v in g.haplotypes[1].variantsPy():
+                    if v in vb:
                         b = vi + 1
                 c.GT.append("%d/%d" % (a, b))
                 c.GQ.append(int(-10.0 * math.log10(max(1e-10, 1.0 - pop.genotypeLikelihoods[ind]))))
                 c.GL.append([-1, -1, -1])
-                c.nReads.append(batch.readCounts(k)[ind])
+                c.nReads.append(readCounts[ind])
             if len(vs) == 1:                                          # GL of AA/AB/BB: variantcaller.pyx:371-378,419-429
-                w = windows[i]
-                h0 = pop.haplotypes[0]
+                h0 = haplotypes[0]
                 rh = chaplotype.Haplotype(chrom, h0.startPosPy, h0.endPosPy, (), refFile, 0)
                 vh = chaplotype.Haplotype(chrom, h0.startPosPy, h0.endPosPy, (vs[0],), refFile, 0)
                 site_items.append((k, rh, vh))
                 site_calls.append(c)
             calls.append(c)
+    t_sites = time.perf_counter()
     if site_items:
         for c, per_ind in zip(site_calls, batch.siteLikelihoods(site_items)):
             for ind, gl in enumerate(per_ind):
@@ -521,5 +542,5 @@ def callRegion(chrom, start, end, readBuffers, refFile, options=None, variants=N
     calls.sort(key=lambda c: c.pos)
     if stats is not None:                                         # seconds per phase of this call
         stats.update(t_candidates=t_cands - t_begin, t_collect=t_collected - t_cands, t_batch=t_ran - t_collected,
-                     t_consume=time.perf_counter() - t_ran)
+                     t_consume=t_sites - t_ran, t_sites=time.perf_counter() - t_sites)
     return calls

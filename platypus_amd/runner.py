@@ -69,7 +69,7 @@ def call_chunks(chunks, args, tmpdir):
     local = threading.local()
     opened = []
 
-    def load(unit):                                       # fetch, inflate, decode, filter and trim: all outside the lock
+    def load(unit, split=1):                              # fetch, inflate, decode, filter and trim: all outside the lock
         (chrom, _, _), s, e = unit
         if not hasattr(local, "readers"):                 # a file handle per helper thread
             local.readers = [bamio.BamReader(b) for b in args.bamFiles.split(",")]
@@ -78,7 +78,8 @@ def call_chunks(chunks, args, tmpdir):
         for r in local.readers:
             t0 = time.perf_counter()
             try:
-                reads = r.fetch(chrom, s, e)
+                # the run's first stretch is read in pieces side by side: nothing can be called before it is there
+                reads = r.fetch(chrom, s, e) if split <= 1 else bamio.fetch_split(r.fileName, chrom, s, e, split)
             except KeyError:                              # this BAM has no such sequence: no reads from it
                 reads = bamio._concat([])
             reads["chrom"] = chrom.encode()
@@ -105,7 +106,7 @@ def call_chunks(chunks, args, tmpdir):
     n_calls, out, current = 0, None, None
     ahead = max(1, args.readAhead)
     with ThreadPoolExecutor(ahead) as pool:
-        pending = collections.deque(pool.submit(load, u) for u in units[:ahead])
+        pending = collections.deque(pool.submit(load, u, ahead if k == 0 else 1) for k, u in enumerate(units[:ahead]))
         for i, (ch, s, e) in enumerate(units):
             t0 = time.perf_counter()
             bufs, cands = pending.popleft().result()
@@ -171,8 +172,9 @@ def main(argv=None):
     ap.add_argument("--workersPerGPU", type=int, default=1,
                     help="host processes per device: the host side (BAM decoding, candidates, windows) dominates the "
                          "run time, so several processes can share one GPU")
-    ap.add_argument("--readAhead", type=int, default=6,
-                    help="buffers prepared ahead of the one being called, each on a helper thread of its own")
+    ap.add_argument("--readAhead", type=int, default=None,
+                    help="buffers prepared ahead of the one being called, each on a helper thread of its own "
+                         "(default: 12 for a single host process, 6 per process otherwise)")
     ap.add_argument("--nCPU", type=int, default=None,
                     help="the reference's option: taken as the total number of host processes when --workersPerGPU is not given")
     ap.add_argument("--labels", default=None, help="regular expression that extracts a sample name from a BAM path")
@@ -203,6 +205,8 @@ def main(argv=None):
     chunks = shard.split_regions(parse_regions(args.regions, fa), args.processRegionSize)
     tmpdir = tempfile.mkdtemp(prefix="platypus_amd_")
     n_workers = max(1, args.nGPU) * max(1, args.workersPerGPU)
+    if args.readAhead is None:
+        args.readAhead = 12 if n_workers == 1 else 6
     weights = None
     if n_workers > 1:                                       # longest first by the reads a chunk holds, as far as the
         from platypus_amd import bamio                      # BAM indexes tell (compressed bytes), else by length

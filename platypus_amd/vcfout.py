@@ -70,15 +70,17 @@ def _num(x):
 
 
 def record(call, refFile):
+    """the text of one body line (vcf.py:710-739): INFO keys in sorted order, one sample column per individual"""
     ref, alts = ref_and_alt(call.chrom, call.pos, call.variants, refFile)
-    info = dict(FR=call.FR, PP=call.PP, TR=call.TR, NF=call.NF, NR=call.NR, TC=[call.TC], TCR=[call.TCR], TCF=[call.TCF],
-                HP=[call.HP], SC=[call.SC.decode()], RMP=[call.RMP], FPV=[call.FPV], RPV=[call.RPV], ABPV=[call.ABPV])
-    if call.MMLQ is not None:
-        info["MMLQ"] = [call.MMLQ]
-    info_text = ";".join("%s=%s" % (k, ",".join(str(x) for x in info[k])) for k in sorted(info))
-    cols = [call.chrom.decode(), str(call.pos + 1), ".", ref.decode(), ",".join(a.decode() for a in alts),
+    join = ",".join
+    info_text = "ABPV=%s;FPV=%s;FR=%s;HP=%s;%sNF=%s;NR=%s;PP=%s;RMP=%s;RPV=%s;SC=%s;TC=%s;TCF=%s;TCR=%s;TR=%s" % (
+        call.ABPV, call.FPV, join(call.FR), call.HP, "" if call.MMLQ is None else "MMLQ=%s;" % (call.MMLQ,),
+        join(map(str, call.NF)), join(map(str, call.NR)), join(call.PP), call.RMP, call.RPV, call.SC.decode(),
+        call.TC, call.TCF, call.TCR, join(map(str, call.TR)))
+    cols = [call.chrom.decode(), str(call.pos + 1), ".", ref.decode(), join([a.decode() for a in alts]),
             str(call.qual), ";".join(call.filters) if call.filters else "PASS", info_text, "GT:GL:GQ:NR"]
-    for i in range(len(call.GT)):
-        cols.append("%s:%s:%s:%s" % (call.GT[i], ",".join(str(x) for x in call.GL[i]),
-                                     call.GQ[i], call.nReads[i]))     # -1 is written as it is: GQ's missing value is "."
+    GT, GL, GQ, NR = call.GT, call.GL, call.GQ, call.nReads
+    for i in range(len(GT)):
+        gl = GL[i]
+        cols.append("%s:%s,%s,%s:%s:%s" % (GT[i], gl[0], gl[1], gl[2], GQ[i], NR[i]))   # a GQ of -1 is written as it is
     return "\t".join(cols)

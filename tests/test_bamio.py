@@ -51,6 +51,12 @@ def test_bam_round_trip_and_region_fetch(tmp_path):
             assert np.array_equal(got[k], want[k]), (s, e, k)
         assert np.all(got["insertSize"] == 0) and np.all(got["matePos"] == -1)
     assert len(rd.fetch(b"other", 0, 500)["pos"]) == 0
+    # the same stretch read in pieces side by side: every record once, in the same order
+    for (s, e, parts) in [(0, G, 7), (40000, 90000, 3), (16384, 16500, 4), (5, 6, 2)]:
+        got, want = bamio.fetch_split(path, b"sim", s, e, parts), rd.fetch(b"sim", s, e)
+        assert set(got) == set(want)
+        for k in want:
+            assert np.array_equal(got[k], want[k]), (s, e, parts, k)
     rd.close()
     # without the index the reader scans
     import os

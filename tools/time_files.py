@@ -45,6 +45,10 @@ def main():
                                                                        time.perf_counter() - t), flush=True)
     out = os.path.join(work, "calls.vcf")
     extra = os.environ.get("TF_ARGS", "").split()               # e.g. "--workersPerGPU 4 --processRegionSize 500000"
+    if os.environ.get("TF_SWITCH"):                             # interpreter lock hand-over interval, seconds
+        sys.setswitchinterval(float(os.environ["TF_SWITCH"]))
+    if os.environ.get("TF_BAM") and os.path.exists(os.environ["TF_BAM"]):
+        pass
     for rep in range(2):
         prof = None
         if rep == 1 and os.environ.get("TF_PROFILE"):
