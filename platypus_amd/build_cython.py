@@ -12,6 +12,9 @@ import sysconfig
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 MODULES = ["cbam", "variant", "calign", "cwindow", "chaplotype", "cgenotype", "cpopulation"]
+# plain Python modules of the region caller, compiled as they are (same source, same semantics, less interpreter
+# time per window); the .py files stay the source, and are what runs where the build has not been done
+PY_MODULES = ["pipeline", "vcfout"]
 PXD = ["samtoolsWrapper.pxd", "platgpu.pxd", "calign.pxd", "cwindow.pxd", "chaplotype.pxd", "cgenotype.pxd", "cpopulation.pxd", "variant.pxd"]
 
 
@@ -19,12 +22,17 @@ def _ext_path(mod):
     return os.path.join(HERE, mod + sysconfig.get_config_var("EXT_SUFFIX"))
 
 
+def _source(src_dir, mod):
+    pyx = os.path.join(src_dir, mod + ".pyx")
+    return pyx if os.path.exists(pyx) else os.path.join(src_dir, mod + ".py")
+
+
 def _stale(mod):
     out = _ext_path(mod)
     if not os.path.exists(out):
         return True
     t = os.path.getmtime(out)
-    deps = [os.path.join(HERE, mod + ".pyx")] + [os.path.join(HERE, p) for p in PXD]
+    deps = [_source(HERE, mod)] + [os.path.join(HERE, p) for p in PXD]
     deps.append(os.path.join(ROOT, "include", "platgpu.h"))
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
@@ -39,7 +47,7 @@ def build(force=False, verbose=True):
     inc = [sysconfig.get_paths()["include"], np.get_include(), os.path.join(ROOT, "include")]
     build_dir = os.path.join(HERE, "_cybuild")
     os.makedirs(build_dir, exist_ok=True)
-    for src_dir, mod in [(HERE, m) for m in MODULES] + TEST_MODULES:
+    for src_dir, mod in [(HERE, m) for m in MODULES + PY_MODULES] + TEST_MODULES:
         out = os.path.join(src_dir, mod + sysconfig.get_config_var("EXT_SUFFIX"))
         if src_dir == HERE:
             stale = _stale(mod)
@@ -49,7 +57,7 @@ def build(force=False, verbose=True):
         if not force and not stale:
             continue
         c_file = os.path.join(build_dir, mod + ".c")
-        cmd = [sys.executable, "-m", "cython", "-3", "-I", ROOT, "-o", c_file, os.path.join(src_dir, mod + ".pyx")]
+        cmd = [sys.executable, "-m", "cython", "-3", "-I", ROOT, "-o", c_file, _source(src_dir, mod)]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd, cwd=ROOT)

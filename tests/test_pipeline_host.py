@@ -295,3 +295,14 @@ def test_other_letters_still_become_candidates():
     gen.addCandidatesFromBuffer(buf)
     got = {(v.refPos, v.added): (v.nSupportingReads, v.nFwdReads) for v in gen.getCandidates()}
     assert got[(215, b"R")] == (2, 1) and got[(220, b"A" if ref[220:221] != b"A" else b"C")] == (2, 1) and len(got) == 2
+
+
+def test_compiled_modules_are_not_older_than_their_sources():
+    """an extension module shadows the source file of the same name: a build that is older than its source
+    would run yesterday's code"""
+    import os
+    from platypus_amd import build_cython as bc
+    for mod in bc.MODULES + bc.PY_MODULES:
+        ext = bc._ext_path(mod)
+        if os.path.exists(ext):
+            assert os.path.getmtime(ext) >= os.path.getmtime(bc._source(bc.HERE, mod)), mod
