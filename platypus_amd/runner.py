@@ -174,7 +174,8 @@ def main(argv=None):
                          "run time, so several processes can share one GPU")
     ap.add_argument("--readAhead", type=int, default=None,
                     help="buffers prepared ahead of the one being called, each on a helper thread of its own "
-                         "(default: 12 for a single host process, 6 per process otherwise)")
+                         "(default: 12 for a single host process, 6 per process otherwise); a shared pool of piece readers "
+                         "under a few buffer threads was measured and is slower")
     ap.add_argument("--nCPU", type=int, default=None,
                     help="the reference's option: taken as the total number of host processes when --workersPerGPU is not given")
     ap.add_argument("--labels", default=None, help="regular expression that extracts a sample name from a BAM path")
