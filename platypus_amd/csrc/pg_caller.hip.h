@@ -29,10 +29,12 @@ namespace pg {
 
 struct WinDesc {
     int32_t n_hap, n_ind, n_reads, n_gen;
+    int32_t ld, reserved;  // row length of the full matrices: n_hap, or n_hap rounded up to whole 128-byte lines when
+                           // the matrix is wider than a wavefront (rows then start on line boundaries)
     int64_t like_base;   // pair index of (haplotype 0, read 0)
     int64_t ioff_base;   // into the concatenated per-individual read offsets (n_ind + 1 entries)
     int64_t cell_base;   // into per-(individual, genotype) arrays: sum of n_ind * n_gen of the windows before
-    int64_t full_base;   // into the full matrices: sum of n_ind * n_hap^2 before
+    int64_t full_base;   // into the full matrices: sum of n_ind * n_hap * ld before
     int64_t hap_base;    // into per-haplotype outputs
     int64_t ind_base;    // into per-individual outputs
 };
@@ -249,9 +251,9 @@ __global__ __launch_bounds__(256) void k_norm(const WinDesc* __restrict__ wins, 
     const double p = exp(cells[c] - from_ordered_bits(win_max[w]));
     cells[c] = p;
     const int a = tri_row_of(g, n), b = a + (int)(g - tri_row_start(a, n));
-    double* F = full + W.full_base + (int64_t)i * n * n;
-    F[(int64_t)a * n + b] = p;
-    F[(int64_t)b * n + a] = p;
+    double* F = full + W.full_base + (int64_t)i * n * W.ld;
+    F[(int64_t)a * W.ld + b] = p;
+    F[(int64_t)b * W.ld + a] = p;
 }
 
 // ---------------------------------------------------------------------------
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(256) void k_norm_tile(const WinDesc* __restrict__ w
     const int i = (int)(blockIdx.x - W.ind_base);
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const double mx = from_ordered_bits(win_max[lo]);
-    double* F = full + W.full_base + (int64_t)i * n * n;
+    double* F = full + W.full_base + (int64_t)i * n * W.ld;
     double* C = cells + W.cell_base + (int64_t)i * W.n_gen;
     for (int r = ty; r < 32; r += 8) {
         const int a = ta * 32 + r, b = tb * 32 + tx;
@@ -289,14 +291,14 @@ __global__ __launch_bounds__(256) void k_norm_tile(const WinDesc* __restrict__ w
             const int64_t c = tri_row_start(a, n) + (b - a);
             p = exp(C[c] - mx);                                              // cpopulation.pyx:732-734
             C[c] = p;
-            F[(int64_t)a * n + b] = p;
+            F[(int64_t)a * W.ld + b] = p;
         }
         tile[r][tx] = p;
     }
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {               // row b2 of the mirror: elements (a2, b2) of the tile's column r
         const int b2 = tb * 32 + r, a2 = ta * 32 + tx;
-        if (a2 < n && b2 < n && a2 < b2) F[(int64_t)b2 * n + a2] = tile[tx][r];
+        if (a2 < n && b2 < n && a2 < b2) F[(int64_t)b2 * W.ld + a2] = tile[tx][r];
     }
 }
 
@@ -324,7 +326,7 @@ __global__ __launch_bounds__(256) void k_norm_tile(const WinDesc* __restrict__ w
 // the rows in row order.
 template <int NC, int INFLIGHT = 16>
 __device__ __forceinline__ double matvec_pass(const double* P, const double* f_src, double* yv,
-                                              int n, int k0, int lane, int r_begin = 0, int r_end = -1)
+                                              int n, int ld, int k0, int lane, int r_begin = 0, int r_end = -1)
 {
     if (r_end < 0) r_end = n;
     constexpr int RU = INFLIGHT / NC;
@@ -338,7 +340,7 @@ __device__ __forceinline__ double matvec_pass(const double* P, const double* f_s
 #pragma unroll
         for (int u = 0; u < RU; ++u)
 #pragma unroll
-            for (int c = 0; c < NC; ++c) pv[u][c] = P[(int64_t)(r + u) * n + kk[c]];
+            for (int c = 0; c < NC; ++c) pv[u][c] = P[(int64_t)(r + u) * ld + kk[c]];
 #pragma unroll
         for (int u = 0; u < RU; ++u) {
             const double fr = f_src[r + u];
@@ -349,7 +351,7 @@ __device__ __forceinline__ double matvec_pass(const double* P, const double* f_s
     for (; r < r_end; ++r) {
         const double fr = f_src[r];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) y[c] += P[(int64_t)r * n + kk[c]] * fr;
+        for (int c = 0; c < NC; ++c) y[c] += P[(int64_t)r * ld + kk[c]] * fr;
     }
     double part = 0.0;
 #pragma unroll
@@ -388,7 +390,7 @@ __device__ __forceinline__ void em_window(double* em_lds, double* s_red, int* s_
     double* const stage = em_lds + (size_t)(3 + 2 * n_wav) * n_max;
     const double* const P_glob = full + W.full_base;
     if (STAGED) {
-        const int tot = W.n_ind * n * n;
+        const int tot = W.n_ind * n * W.ld;
         for (int k = tid; k < tot; k += n_thr) stage[k] = P_glob[k];
     }
 
@@ -408,14 +410,14 @@ __device__ __forceinline__ void em_window(double* em_lds, double* s_red, int* s_
     // y = P_i f_src and csrSum = f_src . y for individual i, by this wavefront: 256 columns
     // per pass, 64 per lane group (see matvec_pass).
     auto matvec = [&](int i, const double* f_src) -> double {
-        const double* P = (STAGED ? (const double*)stage : P_glob) + (int64_t)i * n * n;
+        const double* P = (STAGED ? (const double*)stage : P_glob) + (int64_t)i * n * W.ld;
         double part = 0.0;
         for (int k0 = 0; k0 < n; k0 += 256) {
             const int nc = (n - k0 + 63) >> 6;
-            if (nc >= 4)      part += matvec_pass<4>(P, f_src, yv, n, k0, lane);
-            else if (nc == 3) part += matvec_pass<3>(P, f_src, yv, n, k0, lane);
-            else if (nc == 2) part += matvec_pass<2>(P, f_src, yv, n, k0, lane);
-            else              part += matvec_pass<1>(P, f_src, yv, n, k0, lane);
+            if (nc >= 4)      part += matvec_pass<4>(P, f_src, yv, n, W.ld, k0, lane);
+            else if (nc == 3) part += matvec_pass<3>(P, f_src, yv, n, W.ld, k0, lane);
+            else if (nc == 2) part += matvec_pass<2>(P, f_src, yv, n, W.ld, k0, lane);
+            else              part += matvec_pass<1>(P, f_src, yv, n, W.ld, k0, lane);
         }
         return wave_sum(part);
     };
@@ -464,13 +466,13 @@ __device__ __forceinline__ void em_window(double* em_lds, double* s_red, int* s_
             continue;
         }
         const double s = matvec(i, f_prev);
-        const double* P = (STAGED ? (const double*)stage : P_glob) + (int64_t)i * n * n;
+        const double* P = (STAGED ? (const double*)stage : P_glob) + (int64_t)i * n * W.ld;
         double bv = 0.0;
         int bj = 0x7fffffff;
         for (int a = 0; a < n; ++a) {
             const int64_t row = tri_row_start(a, n);
             for (int b = a + lane; b < n; b += 64) {
-                double v = P[(int64_t)a * n + b] * f_prev[a] * f_prev[b] * (1 + (a != b));   // :847
+                double v = P[(int64_t)a * W.ld + b] * f_prev[a] * f_prev[b] * (1 + (a != b));   // :847
                 if (s > 0.0) v /= s;
                 const int j = (int)(row + b - a);
                 if (bj == 0x7fffffff || v > bv) { bv = v; bj = j; }          // :791 within the lane: j ascending
@@ -574,15 +576,15 @@ __global__ __launch_bounds__(512) void k_em_step(const WinDesc* __restrict__ win
     const double* f_glob = S.f + W.hap_base;
     for (int k = tid; k < n; k += n_thr) f[k] = f_glob[k];
     __syncthreads();
-    const double* P = full + W.full_base + (int64_t)i * n * n;
+    const double* P = full + W.full_base + (int64_t)i * n * W.ld;
     const int rows = (n + n_wav - 1) / n_wav;
     const int r0 = wave * rows < n ? wave * rows : n, r1 = r0 + rows < n ? r0 + rows : n;
     for (int k0 = 0; k0 < n; k0 += 256) {
         const int nc = (n - k0 + 63) >> 6;
-        if (nc >= 4)      matvec_pass<4>(P, f, yv, n, k0, lane, r0, r1);
-        else if (nc == 3) matvec_pass<3>(P, f, yv, n, k0, lane, r0, r1);
-        else if (nc == 2) matvec_pass<2>(P, f, yv, n, k0, lane, r0, r1);
-        else              matvec_pass<1>(P, f, yv, n, k0, lane, r0, r1);
+        if (nc >= 4)      matvec_pass<4>(P, f, yv, n, W.ld, k0, lane, r0, r1);
+        else if (nc == 3) matvec_pass<3>(P, f, yv, n, W.ld, k0, lane, r0, r1);
+        else if (nc == 2) matvec_pass<2>(P, f, yv, n, W.ld, k0, lane, r0, r1);
+        else              matvec_pass<1>(P, f, yv, n, W.ld, k0, lane, r0, r1);
     }
     __syncthreads();
     double part = 0.0;
@@ -686,9 +688,10 @@ __device__ __forceinline__ void em_update_window(const WinDesc& W, const int32_t
 // a transposition, no cross-lane reduction per row beyond three exchange steps.  Every wavefront accumulates
 // into its own copy of y (no atomics: sums are reproducible run to run); the copies are added in wavefront order.
 // Row blocks are dealt back and forth (0..W-1, 2W-1..W, ...): a block near the top has the most tiles.
-// LDS: f [n_pad] | per wavefront: y [n_pad], tile [8][65]; n_pad = n_max rounded up to whole wavefronts.
+// LDS: f [n_pad] | per wavefront: y [n_pad], tile [8][65]; n_pad = the largest sym_pad of the batch's windows.
 constexpr int kSymRows = 8;
 constexpr int kSymTile = 8 * 65;
+constexpr int kSymEdge = 8;           // columns past whole wavefronts that are read as rows of the other half
 
 struct SymTile { int a0, cb; bool ok; };
 
@@ -708,19 +711,20 @@ __device__ __forceinline__ SymTile sym_next(SymTile t, int& round, int wave, int
 // matrix edge re-read the last column and lanes left of the diagonal re-read the diagonal -- lines the row
 // fetches anyway -- and rows past the edge read whatever follows (the next matrix, the zeroed slack behind the
 // last one); what they fetch meets a frequency of zero from the padded copy in LDS, or is discarded.
+// ld: row length of the matrix; lim: rows and columns the tiles cover (see sym_share).
 template <bool DIAG>
-__device__ __forceinline__ void sym_load(double (&p)[kSymRows], const double* __restrict__ P, SymTile t, int n, int lane)
+__device__ __forceinline__ void sym_load(double (&p)[kSymRows], const double* __restrict__ P, SymTile t, int ld, int lim, int lane)
 {
-    const int b = min((t.cb << 6) + lane, n - 1);
-    const double* row = P + (int64_t)t.a0 * n;
+    const int b = min((t.cb << 6) + lane, lim - 1);
+    const double* row = P + (int64_t)t.a0 * ld;
 #pragma unroll
-    for (int r = 0; r < kSymRows; ++r) p[r] = row[(int64_t)r * n + (DIAG ? max(b, min(t.a0 + r, n - 1)) : b)];
+    for (int r = 0; r < kSymRows; ++r) p[r] = row[(int64_t)r * ld + (DIAG ? max(b, min(t.a0 + r, lim - 1)) : b)];
 }
 
-__device__ __forceinline__ void sym_load_any(double (&p)[kSymRows], const double* __restrict__ P, SymTile t, int n, int lane)
+__device__ __forceinline__ void sym_load_any(double (&p)[kSymRows], const double* __restrict__ P, SymTile t, int ld, int lim, int lane)
 {
-    if (t.cb == t.a0 >> 6) sym_load<true>(p, P, t, n, lane);
-    else                   sym_load<false>(p, P, t, n, lane);
+    if (t.cb == t.a0 >> 6) sym_load<true>(p, P, t, ld, lim, lane);
+    else                   sym_load<false>(p, P, t, ld, lim, lane);
 }
 
 // One tile's contribution: the column part goes to the wavefront's copy of y, the row part to the lane's sums z.
@@ -769,43 +773,72 @@ __device__ __forceinline__ void sym_step(const double (&p)[kSymRows], double (&z
     if (last) sym_rows(z, t.a0, lane, yw, tile);
 }
 
-// LDS doubles per vector: the columns rounded up to whole wavefronts (the rows, to whole row blocks, are fewer)
-__host__ __device__ inline int sym_pad(int n_max) { return ((n_max + 63) & ~63); }
+// columns of an n-wide matrix that the step reads as rows of the other half (sym_share)
+__host__ __device__ inline int sym_edge(int n) { return (n >= 64 && (n & 63) <= kSymEdge) ? (n & 63) : 0; }
+// LDS doubles per vector for an n-wide matrix: the tiles' columns rounded up to whole wavefronts (their rows, to
+// whole row blocks, are fewer), and the matrix's own width
+__host__ __device__ inline int sym_pad(int n)
+{
+    const int tiles = (n - sym_edge(n) + 63) & ~63, own = (n + 7) & ~7;
+    return tiles > own ? tiles : own;
+}
 // doubles a step may read past the end of the last matrix
-__host__ __device__ inline int64_t sym_slack(int n_max) { return (int64_t)kSymRows * (n_max + 64); }
+__host__ __device__ inline int64_t sym_slack(int n_max) { return (int64_t)kSymRows * (n_max + 16 + 64); }
 
 // One individual's share of every haplotype's total, from the upper triangle of its matrix.
 __device__ __forceinline__ void sym_share(const WinDesc& W, int i, const double* __restrict__ full, EmState S, int w,
-                                          int n_max, double* em_lds, double* s_part)
+                                          int n_pad, double* em_lds, double* s_part)
 {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);               // the tile walk stays in scalar registers
     const int n_thr = blockDim.x, n_wav = n_thr >> 6;
-    const int n = W.n_hap, n_pad = sym_pad(n_max);
+    const int n = W.n_hap;
     double* f = em_lds;
     double* yw = em_lds + n_pad + (size_t)wave * n_pad;
     double* tile = em_lds + (size_t)(1 + n_wav) * n_pad + (size_t)wave * kSymTile;
-    const double* P = full + W.full_base + (int64_t)i * n * n;
-    const int n_cb = (n + 63) >> 6;
+    const double* P = full + W.full_base + (int64_t)i * n * W.ld;
+    // A matrix a few columns wider than whole wavefronts would pay a tile per row block for those columns.
+    // They are taken from the other half instead: column b of the upper triangle is row b of the lower one,
+    // contiguous in memory.  The tiles then cover the leading lim x lim block, the last n - lim rows are read whole.
+    const int rem = sym_edge(n);
+    const int lim = n - rem;
+    const int n_cb = (lim + 63) >> 6;
     int round = -1;
-    SymTile t0 = sym_next(SymTile{0, 0, false}, round, wave, n_wav, n, n_cb), t1;
+    SymTile t0 = sym_next(SymTile{0, 0, false}, round, wave, n_wav, lim, n_cb), t1;
     double p0[kSymRows], p1[kSymRows], z[kSymRows];
 #pragma unroll
     for (int r = 0; r < kSymRows; ++r) z[r] = 0.0;
-    if (t0.ok) sym_load_any(p0, P, t0, n, lane);         // in flight while the frequencies are staged
+    if (t0.ok) sym_load_any(p0, P, t0, W.ld, lim, lane);    // in flight while the frequencies are staged
     const double* f_glob = S.f + W.hap_base;
     for (int k = tid; k < n_pad; k += n_thr) f[k] = k < n ? f_glob[k] : 0.0;
     for (int k = lane; k < n_pad; k += 64) yw[k] = 0.0;
     __syncthreads();
     // two register sets take turns: the next tile's loads are issued before this tile's values are used
     while (t0.ok) {
-        t1 = sym_next(t0, round, wave, n_wav, n, n_cb);
-        sym_load_any(p1, P, t1.ok ? t1 : t0, n, lane);
+        t1 = sym_next(t0, round, wave, n_wav, lim, n_cb);
+        sym_load_any(p1, P, t1.ok ? t1 : t0, W.ld, lim, lane);
         sym_step(p0, z, t0, !(t1.ok && t1.a0 == t0.a0), lane, f, yw, tile);
         if (!t1.ok) break;
-        t0 = sym_next(t1, round, wave, n_wav, n, n_cb);
-        sym_load_any(p0, P, t0.ok ? t0 : t1, n, lane);
+        t0 = sym_next(t1, round, wave, n_wav, lim, n_cb);
+        sym_load_any(p0, P, t0.ok ? t0 : t1, W.ld, lim, lane);
         sym_step(p1, z, t1, !(t0.ok && t0.a0 == t1.a0), lane, f, yw, tile);
+    }
+    // the last rows, one per wavefront in turn (the last wavefronts first: they have walked the fewest tiles):
+    // element (b, a), a <= b, is P_ab
+    for (int j = 0; j < rem; ++j) {
+        if ((n_wav - 1 - j % n_wav) != wave) continue;
+        const int b = lim + j;
+        const double* row = P + (int64_t)b * W.ld;
+        const double fb = f[b];
+        double acc = 0.0;
+        for (int a0 = 0; a0 <= b; a0 += 64) {
+            const int a = a0 + lane;
+            const double v = a <= b ? row[a] : 0.0;
+            acc += v * f[min(a, n_pad - 1)];                                 // y_b += P_ab f_a, the diagonal included
+            if (a < b) yw[a] += v * fb;                                      // y_a += P_ab f_b
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) yw[b] += acc;
     }
     __syncthreads();
     double part = 0.0;
@@ -828,9 +861,10 @@ __device__ __forceinline__ void sym_share(const WinDesc& W, int i, const double*
     }
 }
 
-// grid (window, individual).  Dynamic LDS: the layout above, and at least one byte per individual of a window.
+// grid (window, individual).  Dynamic LDS: the layout above (n_pad from the host), and at least one byte per
+// individual of a window.
 __global__ __launch_bounds__(1024) void k_em_step_sym(const WinDesc* __restrict__ wins, const int32_t* __restrict__ ioff,
-                                                      const double* __restrict__ full, EmState S, int n_max,
+                                                      const double* __restrict__ full, EmState S, int n_pad,
                                                       int max_iters)
 {
     extern __shared__ double em_lds[];
@@ -845,7 +879,7 @@ __global__ __launch_bounds__(1024) void k_em_step_sym(const WinDesc* __restrict_
     const int32_t* io = ioff + W.ioff_base;
     const int tid = threadIdx.x;
     if (io[i + 1] != io[i])                                                  // cpopulation.pyx:834-835
-        sym_share(W, i, full, S, w, n_max, em_lds, s_part);
+        sym_share(W, i, full, S, w, n_pad, em_lds, s_part);
     // The window's last workgroup to get here does the window's update: every workgroup's shares have reached
     // device scope before it counts itself (its wavefronts wait for their stores, then the barrier), the
     // frequencies that are replaced have been read by all of them, and nothing reads the new ones before the
@@ -895,15 +929,15 @@ __global__ __launch_bounds__(512) void k_em_calls(const WinDesc* __restrict__ wi
     const double* f_glob = S.f_prev + W.hap_base;
     for (int k = tid; k < n; k += n_thr) f[k] = f_glob[k];
     __syncthreads();
-    const double* P = full + W.full_base + (int64_t)i * n * n;
+    const double* P = full + W.full_base + (int64_t)i * n * W.ld;
     const int rows = (n + n_wav - 1) / n_wav;
     const int r0 = wave * rows < n ? wave * rows : n, r1 = r0 + rows < n ? r0 + rows : n;
     for (int k0 = 0; k0 < n; k0 += 256) {
         const int nc = (n - k0 + 63) >> 6;
-        if (nc >= 4)      matvec_pass<4>(P, f, yv, n, k0, lane, r0, r1);
-        else if (nc == 3) matvec_pass<3>(P, f, yv, n, k0, lane, r0, r1);
-        else if (nc == 2) matvec_pass<2>(P, f, yv, n, k0, lane, r0, r1);
-        else              matvec_pass<1>(P, f, yv, n, k0, lane, r0, r1);
+        if (nc >= 4)      matvec_pass<4>(P, f, yv, n, W.ld, k0, lane, r0, r1);
+        else if (nc == 3) matvec_pass<3>(P, f, yv, n, W.ld, k0, lane, r0, r1);
+        else if (nc == 2) matvec_pass<2>(P, f, yv, n, W.ld, k0, lane, r0, r1);
+        else              matvec_pass<1>(P, f, yv, n, W.ld, k0, lane, r0, r1);
     }
     __syncthreads();
     double part = 0.0;
@@ -923,7 +957,7 @@ __global__ __launch_bounds__(512) void k_em_calls(const WinDesc* __restrict__ wi
     for (int a = r0; a < r1; ++a) {
         const int64_t row = tri_row_start(a, n);
         for (int b = a + lane; b < n; b += 64) {
-            double v = P[(int64_t)a * n + b] * f[a] * f[b] * (1 + (a != b));   // cpopulation.pyx:847
+            double v = P[(int64_t)a * W.ld + b] * f[a] * f[b] * (1 + (a != b));   // cpopulation.pyx:847
             if (s > 0.0) v /= s;
             const int j = (int)(row + b - a);
             if (bj == 0x7fffffff || v > bv) { bv = v; bj = j; }             // cpopulation.pyx:791
@@ -1090,12 +1124,12 @@ __global__ __launch_bounds__(64) void k_var_post(const WinDesc* __restrict__ win
     double slp_var = 0.0, slp_novar = 0.0;
     for (int i = 0; i < W.n_ind; ++i) {
         if (io[i + 1] == io[i]) continue;                                    // :590-591
-        const double* P = full + W.full_base + (int64_t)i * n * n;
+        const double* P = full + W.full_base + (int64_t)i * n * W.ld;
         double pv = 0.0, pn = 0.0;
         for (int k = lane; k < n; k += 64) {
             double y = 0.0, yp = 0.0;
             for (int r = 0; r < n; ++r) {
-                const double p = P[(int64_t)r * n + k];
+                const double p = P[(int64_t)r * W.ld + k];
                 y += p * f[r];
                 yp += p * fp[r];
             }

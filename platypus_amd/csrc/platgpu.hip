@@ -153,7 +153,7 @@ struct pg_ctx {
 
     // windows of the genotype / EM stage
     int n_windows = 0, max_win_haps = 0, max_win_inds = 0;
-    int64_t max_win_full = 0;             // largest n_ind * n_hap^2 of a window
+    int64_t max_win_full = 0;             // largest n_ind * n_hap * ld of a window
     int64_t win_cells = 0, win_full = 0, win_haps_total = 0, win_inds_total = 0;
     bool caller_done = false;
     std::vector<pg::WinDesc> h_wins;
@@ -934,12 +934,13 @@ int pg_windows_upload(pg_ctx* c, int nw, const int32_t* n_haps, const int32_t* n
             return fail(c, PG_ERR_INVALID, "window %d reaches outside the pair list", w);
         pg::WinDesc& W = wins[w];
         W.n_hap = nh; W.n_ind = ni; W.n_reads = nr; W.n_gen = nh * (nh + 1) / 2;
+        W.ld = nh > 64 ? (nh + 15) & ~15 : nh; W.reserved = 0;
         W.like_base = like_base[w]; W.ioff_base = ioff; W.cell_base = cells; W.full_base = full;
         W.hap_base = haps; W.ind_base = inds;
         share_base[w] = share; share += (int64_t)ni * nh;
-        ioff += ni + 1; cells += (int64_t)ni * W.n_gen; full += (int64_t)ni * nh * nh; haps += nh; inds += ni;
+        ioff += ni + 1; cells += (int64_t)ni * W.n_gen; full += (int64_t)ni * nh * W.ld; haps += nh; inds += ni;
         max_h = std::max(max_h, nh); max_i = std::max(max_i, ni);
-        max_full = std::max(max_full, (int64_t)ni * nh * nh);
+        max_full = std::max(max_full, (int64_t)ni * nh * W.ld);
     }
     PG_HIP(c, hipSetDevice(c->device));
     PG_HIP(c, c->d_wins.reserve((size_t)nw + 1)); PG_HIP(c, c->d_ioff.reserve((size_t)ioff + 1));
@@ -1052,7 +1053,9 @@ int pg_caller_launch(pg_ctx* c, int max_iters) {
         const bool sym = c->em_step >= 0 ? c->em_step == 1 : n_max > 64;
         // sixteen wavefronts per (window, individual) where LDS allows: the fewer tiles a wavefront walks one after
         // the other, the shorter the last workgroups of a launch run alone
-        auto sym_lds = [&](int waves) { return ((size_t)(1 + waves) * pg::sym_pad(n_max) + (size_t)waves * pg::kSymTile) * sizeof(double); };
+        int n_pad = 8;
+        for (const pg::WinDesc& W : c->h_wins) n_pad = std::max(n_pad, pg::sym_pad(W.n_hap));
+        auto sym_lds = [&](int waves) { return ((size_t)(1 + waves) * n_pad + (size_t)waves * pg::kSymTile) * sizeof(double); };
         int sym_waves = c->em_step_waves > 0 ? c->em_step_waves : 8;
         while (sym_waves > 1 && sym_lds(sym_waves) > 160 * 1024) sym_waves >>= 1;
         const int sym_threads = 64 * sym_waves;
@@ -1076,7 +1079,7 @@ int pg_caller_launch(pg_ctx* c, int max_iters) {
             }
             for (int it = 8 * b; it < std::min(max_iters, 8 * b + 8); ++it) {
                 if (sym) {            // the last workgroup of a window to finish does the window's update
-                    hipLaunchKernelGGL(pg::k_em_step_sym, dim3(c->n_windows, c->max_win_inds), dim3(sym_threads), lds_sym, c->stream, c->d_wins.p, c->d_ioff.p, c->d_full.p, S, n_max, max_iters);
+                    hipLaunchKernelGGL(pg::k_em_step_sym, dim3(c->n_windows, c->max_win_inds), dim3(sym_threads), lds_sym, c->stream, c->d_wins.p, c->d_ioff.p, c->d_full.p, S, n_pad, max_iters);
                 } else {
                     hipLaunchKernelGGL(pg::k_em_step, dim3(c->n_windows, c->max_win_inds), dim3(step_threads), lds_step, c->stream, c->d_wins.p, c->d_ioff.p, c->d_full.p, S, n_max);
                     hipLaunchKernelGGL(pg::k_em_update, dim3(c->n_windows), dim3(256), lds_update, c->stream, c->d_wins.p, c->d_ioff.p, S, max_iters);

@@ -182,6 +182,10 @@ def test_em_step_kernels_against_checker(step):
     run_case(n_windows=3, H=65, R=90, n_ind=5, seed=45, empty=0, read_len=40, hap_len=200, options=opt)
     run_case(n_windows=2, H=130, R=80, n_ind=3, seed=46, read_len=40, hap_len=200, options=opt + [("em_step_waves", "16")])
     run_case(n_windows=4, H=9, R=40, n_ind=4, seed=47, empty=3, options=opt + [("em_step_waves", "1")])
+    # widths just past whole wavefronts (the last columns come from the other half's rows), and the widest of those
+    run_case(n_windows=2, H=129, R=60, n_ind=3, seed=48, read_len=40, hap_len=200, options=opt)
+    run_case(n_windows=2, H=80, R=60, n_ind=2, seed=49, empty=1, read_len=40, hap_len=200, options=opt + [("em_step_waves", "3")])
+    run_case(n_windows=1, H=64, R=60, n_ind=2, seed=50, read_len=40, hap_len=200, options=opt)
 
 
 def test_em_iteration_cap():
