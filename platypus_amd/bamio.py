@@ -134,7 +134,7 @@ class BamReader(object):
         while True:
             chunk = self.f.read(4 << 20)
             raw = raw + chunk if raw else chunk
-            # whole blocks inflated behind what the last round left over, then decoded: both in C without the
+            # whole blocks inflated behind what the previous pass left over, then decoded: both in C without the
             # interpreter lock, so a helper thread doing this does not hold up the thread that calls variants
             data, eaten = cbam.inflateBlocks(np.frombuffer(raw, dtype=np.uint8), tail)
             raw = raw[eaten:]
