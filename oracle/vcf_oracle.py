@@ -252,6 +252,8 @@ def binomial(x, size, prob):
 
 def py2_round(x, nd=0):
     """round() of Python 2: half away from zero, on the value printed to nd + enough digits as the C library does"""
+    if math.isinf(x) or math.isnan(x):                 # returned as they are (a log-likelihood of -inf is printed "-inf")
+        return x
     m = 10.0 ** nd
     y = x * m
     r = math.floor(abs(y) + 0.5)

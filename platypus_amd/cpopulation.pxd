@@ -30,5 +30,6 @@ cdef class Caller:
 # platypus/variantcaller.pyx:116-187 into device batches)
 cdef class WindowBatch:
     cdef list windows
+    cdef list pairBase
     cdef public list populations
     cdef public dict timings

@@ -257,6 +257,7 @@ cdef class WindowBatch:
     def __init__(self):
         self.windows = []
         self.populations = []
+        self.pairBase = []
         self.timings = {}
 
     def __len__(self):
@@ -502,6 +503,7 @@ cdef class WindowBatch:
             for w in range(5):                                    # anchor, alignment, genotype, setup, EM (platgpu.h)
                 kms[w] = 0.0
                 pg_kernel_time_ms(ctx, w, &kms[w])
+            self.pairBase = [base[w] for w in range(nW)]          # pair index of (haplotype 0, read 0) of every window
             hi = 0; ii = 0; ci = 0
             for w in range(nW):
                 haps, bufs, counts, firsts = self.windows[w]
@@ -637,6 +639,56 @@ cdef class WindowBatch:
         finally:
             free(hoff); free(hstart); free(hvl); free(hbuf); free(roff); free(rpos); free(rmq); free(sbuf); free(qbuf)
             free(b_hlo); free(b_nh); free(b_rlo); free(b_nr); free(base); free(g1); free(g2); free(gn); free(gout)
+        return out
+
+    def siteLikelihoodsResident(self, list items):
+        """siteLikelihoods for sites whose two haplotypes are among their window's own: `items` is a list of
+        (window index, index of the reference haplotype, index of the variant haplotype) into the window's
+        haplotype list.  The fresh haplotypes the reference builds there (variantcaller.pyx:371-378) span the
+        window's haplotypes' coordinates and carry the same variants, i.e. they are the same sequences against
+        the same reads: their likelihood rows are the ones `run` left on the device, and only the AA / AB / BB
+        sums are computed.  Valid until the next alignment launch of this process."""
+        cdef pg_ctx* ctx = deviceContext()
+        cdef int nItems = len(items), it, w, hr, hv, cnt
+        cdef int64_t nRows = 0, row = 0, n, nTot, b0, bRef, bVar
+        cdef Population pop
+        cdef list out = []
+        if nItems == 0:
+            return []
+        for w, hr, hv in items:
+            pop = self.populations[w]
+            if pop.generation != g_generation:
+                raise PlatGpuError("the batch's results have left the device")
+            nRows += 3 * len(self.windows[w][1])
+        cdef int64_t* g1 = <int64_t*>malloc((nRows + 1) * sizeof(int64_t))
+        cdef int64_t* g2 = <int64_t*>malloc((nRows + 1) * sizeof(int64_t))
+        cdef int32_t* gn = <int32_t*>malloc((nRows + 1) * sizeof(int32_t))
+        cdef double* gout = <double*>malloc((nRows + 1) * sizeof(double))
+        try:
+            for it in range(nItems):
+                w, hr, hv = items[it]
+                counts = self.windows[w][2]
+                nTot = sum(counts)
+                b0 = self.pairBase[w]
+                n = 0
+                for cnt in counts:
+                    bRef = b0 + hr * nTot + n
+                    bVar = b0 + hv * nTot + n
+                    g1[row] = bRef; g2[row] = bRef; gn[row] = cnt          # AA
+                    g1[row + 1] = bRef; g2[row + 1] = bVar; gn[row + 1] = cnt  # AB
+                    g1[row + 2] = bVar; g2[row + 2] = bVar; gn[row + 2] = cnt  # BB
+                    row += 3
+                    n += cnt
+            check(ctx, pg_genotype_loglik(ctx, nRows, g1, g2, gn, gout))
+            row = 0
+            for it in range(nItems):
+                res = []
+                for cnt in self.windows[items[it][0]][2]:
+                    res.append((gout[row], gout[row + 1], gout[row + 2]) if cnt > 0 else None)
+                    row += 3
+                out.append(res)
+        finally:
+            free(g1); free(g2); free(gn); free(gout)
         return out
 
     def posteriors(self, list items):

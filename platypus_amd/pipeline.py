@@ -458,7 +458,7 @@ def callRegion(chrom, start, end, readBuffers, refFile, options=None, variants=N
     perWin = {}
     for (k, v), p in zip(items, posts):
         perWin.setdefault(k, []).append((v, p))
-    calls, site_items, site_calls = [], [], []
+    calls, site_items, site_calls, resident_items, resident_calls = [], [], [], [], []
     minPosterior = options.minPosterior
     for k, i in enumerate(order):
         mine = perWin.get(k)
@@ -527,13 +527,31 @@ def callRegion(chrom, start, end, readBuffers, refFile, options=None, variants=N
                 c.GL.append([-1, -1, -1])
                 c.nReads.append(readCounts[ind])
             if len(vs) == 1:                                          # GL of AA/AB/BB: variantcaller.pyx:371-378,419-429
-                h0 = haplotypes[0]
-                rh = chaplotype.Haplotype(chrom, h0.startPosPy, h0.endPosPy, (), refFile, 0)
-                vh = chaplotype.Haplotype(chrom, h0.startPosPy, h0.endPosPy, (vs[0],), refFile, 0)
-                site_items.append((k, rh, vh))
-                site_calls.append(c)
+                # The reference builds a fresh reference haplotype and a fresh haplotype with this variant over the
+                # window haplotypes' span: the same sequences as the window's own first haplotype and its haplotype
+                # of this variant alone, whose likelihoods the batch has left on the device.
+                hv1 = -1
+                if not hv[0]:
+                    for h, hvs in enumerate(hv):
+                        if len(hvs) == 1 and hvs[0] == vs[0]:
+                            hv1 = h
+                            break
+                if hv1 > 0:
+                    resident_items.append((k, 0, hv1))
+                    resident_calls.append(c)
+                else:                                                 # (that haplotype was merged with an equal sequence)
+                    h0 = haplotypes[0]
+                    rh = chaplotype.Haplotype(chrom, h0.startPosPy, h0.endPosPy, (), refFile, 0)
+                    vh = chaplotype.Haplotype(chrom, h0.startPosPy, h0.endPosPy, (vs[0],), refFile, 0)
+                    site_items.append((k, rh, vh))
+                    site_calls.append(c)
             calls.append(c)
     t_sites = time.perf_counter()
+    if resident_items:                                                # before anything else is aligned
+        for c, per_ind in zip(resident_calls, batch.siteLikelihoodsResident(resident_items)):
+            for ind, gl in enumerate(per_ind):
+                if gl is not None and c.GT[ind] != "./.":
+                    c.GL[ind] = [round(x, 2) for x in gl]
     if site_items:
         for c, per_ind in zip(site_calls, batch.siteLikelihoods(site_items)):
             for ind, gl in enumerate(per_ind):
