@@ -21,6 +21,7 @@ source text.  Where the reference's result depends on the iteration order of a P
 cpopulation.pyx:263; `for v in FILTER`, cpopulation.pyx:450) no restatement can be exact: the order
 used here is stated at each place (haplotypes in the order they are made; variants sorted).
 """
+import decimal
 import math
 from itertools import combinations
 
@@ -251,15 +252,12 @@ def binomial(x, size, prob):
 
 
 def py2_round(x, nd=0):
-    """round() of Python 2: half away from zero, on the value printed to nd + enough digits as the C library does"""
+    """round() of Python 2.7: the exact binary value rounded to nd decimals, halves away from zero
+    (floatobject.c float_round: correctly rounded through dtoa, not by scaling)"""
     if math.isinf(x) or math.isnan(x):                 # returned as they are (a log-likelihood of -inf is printed "-inf")
         return x
-    m = 10.0 ** nd
-    y = x * m
-    r = math.floor(abs(y) + 0.5)
-    if abs(y) - math.floor(abs(y)) == 0.5 and abs(y) < 2.0 ** 52:
-        r = math.floor(abs(y)) + 1.0
-    return math.copysign(r, x) / m if nd else math.copysign(r, x)
+    q = decimal.Decimal(x).quantize(decimal.Decimal(1).scaleb(-nd), rounding=decimal.ROUND_HALF_UP)
+    return float(q)
 
 
 def py2_str(x):

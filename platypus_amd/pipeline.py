@@ -225,8 +225,10 @@ class Call(object):
 
 
 def _round_half_up(x):
-    """round() of the Python 2 the reference runs on (halves away from zero), for x >= 0"""
-    return int(math.floor(x + 0.5))
+    """round() of the Python 2 the reference runs on (halves away from zero), for x >= 0; the fraction
+    x - floor(x) is exact, x + 0.5 would not always be"""
+    r = math.floor(x)
+    return int(r) + 1 if x - r >= 0.5 else int(r)
 
 
 _LOG_FACT = {}
