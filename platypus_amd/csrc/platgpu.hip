@@ -1049,14 +1049,21 @@ int pg_caller_launch(pg_ctx* c, int max_iters) {
         const int step_threads = n_max <= 64 ? 64 : (n_max <= 128 ? 256 : 512);
         const size_t lds_step = (size_t)(1 + step_threads / 64) * n_max * sizeof(double);
         PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_em_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step));
-        // matrices wider than a wavefront are stepped from their upper triangle alone (half the bytes)
-        const bool sym = c->em_step >= 0 ? c->em_step == 1 : n_max > 64;
-        // sixteen wavefronts per (window, individual) where LDS allows: the fewer tiles a wavefront walks one after
-        // the other, the shorter the last workgroups of a launch run alone
+        // all but narrow matrices are stepped from their upper triangle alone (half the bytes; measured better from
+        // about 24 haplotypes on)
+        const bool sym = c->em_step >= 0 ? c->em_step == 1 : n_max > 24;
         int n_pad = 8;
         for (const pg::WinDesc& W : c->h_wins) n_pad = std::max(n_pad, pg::sym_pad(W.n_hap));
         auto sym_lds = [&](int waves) { return ((size_t)(1 + waves) * n_pad + (size_t)waves * pg::kSymTile) * sizeof(double); };
-        int sym_waves = c->em_step_waves > 0 ? c->em_step_waves : 8;
+        // Wavefronts per (window, individual): about ten tiles of the widest matrix each.  Fewer tiles per wavefront
+        // and the workgroup's start and end (staging the frequencies, adding the copies of y) weigh more than the
+        // walk; more, and the last workgroups of a launch run long on their own (measured at 30 to 257 haplotypes).
+        int sym_tiles = 0;
+        {
+            const int lim = n_max - pg::sym_edge(n_max), n_cb = (lim + 63) >> 6;
+            for (int a0 = 0; a0 < lim; a0 += pg::kSymRows) sym_tiles += n_cb - (a0 >> 6);
+        }
+        int sym_waves = c->em_step_waves > 0 ? c->em_step_waves : (sym_tiles < 12 ? 1 : sym_tiles < 22 ? 2 : sym_tiles < 60 ? 4 : 8);
         while (sym_waves > 1 && sym_lds(sym_waves) > 160 * 1024) sym_waves >>= 1;
         const int sym_threads = 64 * sym_waves;
         const size_t lds_sym = std::max(sym_lds(sym_waves), (size_t)((c->max_win_inds + 15) & ~15));
