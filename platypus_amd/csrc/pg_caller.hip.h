@@ -992,24 +992,26 @@ __global__ __launch_bounds__(256) void k_em_update(const WinDesc* __restrict__ w
 
 // ---------------------------------------------------------------------------
 // k_em_small: the same computation for windows of at most 8 haplotypes (the
-// usual single-sample window has 2-4), one wavefront per window, everything in
-// registers.  Lane l < n^2 owns the matrix element (r, k) = (l / n, l % n); the
+// usual window has 2-4), one wavefront per window, everything in registers.
+// A matrix has n^2 <= 64 elements.  With several individuals and n <= 5,
+// G = 64 / n^2 >= 2 individuals are taken side by side, lane l of slot
+// g = l / n^2 owning element (r, k) = (e / n, e % n), e = l % n^2, of individual
+// s * G + g in step s; otherwise one individual at a time, lane = element.  The
 // product sums its rows in row order through lane reads, the frequencies live
-// replicated in the lanes.  Every sum has the shape it has in k_em, so the two
-// kernels return the same doubles.
+// replicated in the lanes, and the individuals' shares are added to the totals
+// in individual order.  Every sum has the shape it has in k_em with one
+// individual per wavefront, so the kernels return the same doubles.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_em_small(const WinDesc* __restrict__ wins, int n_win,
-                                                  const int32_t* __restrict__ ioff,
-                                                  const double* __restrict__ full,
-                                                  int max_iters,
-                                                  double* __restrict__ freq_out, int32_t* __restrict__ iters_out,
-                                                  double* __restrict__ change_out, int32_t* __restrict__ best_gen,
-                                                  double* __restrict__ best_val)
+// One individual at a time: lane l < n^2 owns the matrix element (r, k) = (l / n, l % n) (windows of 6 to 8
+// haplotypes, whose matrices fill most of a wavefront, and windows with one individual).
+__device__ __forceinline__ void em_small_one(const WinDesc& W, int w, int lane,
+                                             const int32_t* __restrict__ ioff,
+                                             const double* __restrict__ full,
+                                             int max_iters,
+                                             double* __restrict__ freq_out, int32_t* __restrict__ iters_out,
+                                             double* __restrict__ change_out, int32_t* __restrict__ best_gen,
+                                             double* __restrict__ best_val)
 {
-    const int w = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256u + threadIdx.x) >> 6));
-    if (w >= n_win) return;
-    const int lane = threadIdx.x & 63;
-    const WinDesc W = wins[w];
     const int n = W.n_hap, nn = n * n;
     const int32_t* io = ioff + W.ioff_base;
     const bool live = lane < nn;
@@ -1082,6 +1084,134 @@ __global__ __launch_bounds__(256) void k_em_small(const WinDesc* __restrict__ wi
         }
         if (lane == 0) { best_gen[W.ind_base + i] = bj; best_val[W.ind_base + i] = bv; }
     }
+}
+
+// G = 64 / n^2 >= 2 individuals side by side (windows of up to 5 haplotypes with several individuals).
+__device__ __forceinline__ void em_small_slots(const WinDesc& W, int w, int lane,
+                                               const int32_t* __restrict__ ioff,
+                                               const double* __restrict__ full,
+                                               int max_iters,
+                                               double* __restrict__ freq_out, int32_t* __restrict__ iters_out,
+                                               double* __restrict__ change_out, int32_t* __restrict__ best_gen,
+                                               double* __restrict__ best_val)
+{
+    const int n = W.n_hap, nn = n * n;
+    const int G = 64 / nn, steps = (W.n_ind + G - 1) / G;
+    const int32_t* io = ioff + W.ioff_base;
+    const bool live = lane < G * nn;
+    const int slot = live ? lane / nn : 0, sb = slot * nn, e = live ? lane - sb : 0;
+    const int r = e / n, k = e % n;
+    const double* Pw = full + W.full_base;
+    int n_with_data = 0;
+    for (int i = 0; i < W.n_ind; ++i) n_with_data += io[i + 1] != io[i];
+    double eps = 1.0 / (W.n_ind * 2 * 2);                                    // cpopulation.pyx:751
+    eps = eps < 1e-3 ? eps : 1e-3;
+    double max_change = eps + 1;
+    int iters = 0;
+    double fk = 1.0 / n, fr = 1.0 / n, fk_prev = fk, fr_prev = fr;           // f[k], f[r] of this lane
+
+    // element of the slot's individual in step s (zero past the last individual), and whether it has reads
+    auto element = [&](int s) -> double {
+        const int i = s * G + slot;
+        return (live && i < W.n_ind) ? Pw[(int64_t)i * nn + e] : 0.0;
+    };
+    auto with_data = [&](int s) -> int {
+        const int i = s * G + slot;
+        return (live && i < W.n_ind) ? (int)(io[i + 1] != io[i]) : 0;
+    };
+    const double P0 = element(0);                                             // step 0 stays in a register
+    const int D0 = with_data(0);
+
+    // y_k (valid in the lanes with r == 0 of every slot) and csrSum of every slot's individual.  The sum over
+    // the slot's n lanes has the shape of a wavefront sum over lanes 0..7 (pairs, fours, eight).
+    auto matvec = [&](double p, double f_r, double f_k, double& y) -> double {
+        const double t = p * f_r;
+        y = 0.0;
+        for (int rr = 0; rr < n; ++rr) y += __shfl(t, sb + rr * n + k);     // rows in row order
+        const double val = (live && r == 0) ? f_k * y : 0.0;
+        double v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const double got = __shfl(val, sb + (j < n ? j : 0));
+            v[j] = j < n ? got : 0.0;
+        }
+        return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    };
+
+    while (max_change > eps && iters < max_iters) {                          // :766-768
+        double acc = 0.0;                                                    // total of this lane's haplotype k
+        double p_next = P0;
+        int d_next = D0;
+        for (int s = 0; s < steps; ++s) {
+            const double p = p_next;
+            const int has = d_next;
+            if (s + 1 < steps) { p_next = element(s + 1); d_next = with_data(s + 1); }   // in flight during this step
+            double y;
+            const double sum = matvec(p, fr, fk, y);
+            const double t = 2.0 * fk * y;
+            const double share = sum > 0.0 ? t / sum : t;                    // :852-854, in the lanes with r == 0
+            for (int g = 0; g < G && s * G + g < W.n_ind; ++g) {             // the slots in individual order
+                const double sh = __shfl(share, g * nn + k);
+                if (__shfl(has, g * nn)) acc += sh;                          // :834-835: no reads, no term
+            }
+        }
+        const double nf = (0.0 + acc) / (2 * n_with_data);                   // :883
+        const double ch = wave_max(lane < n ? fabs(fk - nf) : 0.0);          // :885-888 (lanes 0..n-1: every k once)
+        max_change = ch;
+        fk_prev = fk; fr_prev = fr;
+        fk = nf;
+        fr = __shfl(nf, r);                                                  // lane r holds haplotype r's
+        ++iters;
+    }
+    if (lane < n) freq_out[W.hap_base + lane] = fk;
+    if (lane == 0) { iters_out[w] = iters; change_out[w] = max_change; }
+
+    for (int s = 0; s < steps; ++s) {                                        // :773-797
+        const int i = s * G + slot;
+        const bool mine = live && i < W.n_ind;
+        const double p = s == 0 ? P0 : element(s);
+        const int has = s == 0 ? D0 : with_data(s);
+        double y;
+        const double sum = matvec(p, fr_prev, fk_prev, y);
+        double bv = 0.0;
+        int bj = 0x7fffffff;
+        if (mine && r <= k) {                                                // genotype (a, b) = (r, k)
+            double v = p * fr_prev * fk_prev * (1 + (r != k));               // :847
+            if (sum > 0.0) v /= sum;
+            bv = v;
+            bj = (int)(tri_row_start(r, n) + k - r);
+        }
+        double best_v = 0.0;                                                 // largest value of the slot, the first
+        int best_j = 0x7fffffff;                                             // genotype among equal ones
+        for (int jj = 0; jj < nn; ++jj) {
+            const double ov = __shfl(bv, sb + jj);
+            const int oj = __shfl(bj, sb + jj);
+            if (oj != 0x7fffffff && (best_j == 0x7fffffff || ov > best_v || (ov == best_v && oj < best_j))) { best_v = ov; best_j = oj; }
+        }
+        if (mine && e == 0) {
+            if (!has) { best_gen[W.ind_base + i] = -1; best_val[W.ind_base + i] = 0.0; }
+            else if (iters == 0) { best_gen[W.ind_base + i] = 0; best_val[W.ind_base + i] = 0.0; }
+            else { best_gen[W.ind_base + i] = best_j; best_val[W.ind_base + i] = best_v; }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_em_small(const WinDesc* __restrict__ wins, int n_win,
+                                                  const int32_t* __restrict__ ioff,
+                                                  const double* __restrict__ full,
+                                                  int max_iters,
+                                                  double* __restrict__ freq_out, int32_t* __restrict__ iters_out,
+                                                  double* __restrict__ change_out, int32_t* __restrict__ best_gen,
+                                                  double* __restrict__ best_val)
+{
+    const int w = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256u + threadIdx.x) >> 6));
+    if (w >= n_win) return;
+    const int lane = threadIdx.x & 63;
+    const WinDesc W = wins[w];
+    if (W.n_ind > 1 && W.n_hap * W.n_hap <= 32)
+        em_small_slots(W, w, lane, ioff, full, max_iters, freq_out, iters_out, change_out, best_gen, best_val);
+    else
+        em_small_one(W, w, lane, ioff, full, max_iters, freq_out, iters_out, change_out, best_gen, best_val);
 }
 
 // ---------------------------------------------------------------------------

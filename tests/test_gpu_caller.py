@@ -139,15 +139,19 @@ def test_window_errors():
         ctx.close()
 
 
-def test_small_window_kernel_equals_general_kernel():
-    """Windows of at most 8 haplotypes take a one-wavefront-per-window kernel; its sums have the
-    shape of the general kernel's, so both return the same doubles."""
+@pytest.mark.parametrize("H,n_ind", [(7, 3), (2, 16), (3, 9), (4, 11), (5, 5), (6, 4), (8, 2), (2, 1), (4, 16)])
+def test_small_window_kernel_equals_general_kernel(H, n_ind):
+    """Windows of at most 8 haplotypes take a one-wavefront-per-window kernel that handles 64 / H^2 individuals
+    side by side; its sums have the shape of the general kernel's, so both return the same doubles -- for one
+    individual per step (H >= 6) as for sixteen (H = 2), whole steps or a ragged last one, with individuals that
+    have no reads.  (Up to 16 individuals: beyond that the general kernel gives a wavefront several individuals
+    and adds their shares per wavefront first.)"""
     from platypus_amd import native
-    H, R, n_ind, nw = 7, 40, 3, 50
+    R, nw = 4 * n_ind + 24, 50
     b = synth.make_batch(n_windows=nw, haps_per_window=H, reads_per_window=R, read_len=50, hap_len=260,
-                         indel_hap_frac=0.3, seed=21)
+                         indel_hap_frac=0.3, seed=21 + H)
     rng = np.random.default_rng(3)
-    offs = np.concatenate([split_reads(rng, R, n_ind, 1 if w % 4 == 0 else None) for w in range(nw)])
+    offs = np.concatenate([split_reads(rng, R, n_ind, (w % max(1, n_ind)) if w % 4 == 0 else None) for w in range(nw)])
     out = {}
     for which in ("small", "big"):
         ctx = native.AlignContext(0)
@@ -162,6 +166,15 @@ def test_small_window_kernel_equals_general_kernel():
             ctx.close()
     for k in ("freq", "iters", "max_change", "best_gen", "best_val", "post"):
         assert np.array_equal(out["small"][k], out["big"][k]), k
+
+
+def test_small_windows_with_many_individuals_against_checker():
+    """the side-by-side slots of the small-window kernel over many steps: 2 to 5 haplotypes, 23 to 70 individuals,
+    some of them without reads"""
+    run_case(n_windows=12, H=2, R=160, n_ind=70, seed=61, empty=33)
+    run_case(n_windows=12, H=3, R=120, n_ind=41, seed=62, empty=0)
+    run_case(n_windows=12, H=4, R=120, n_ind=23, seed=63, empty=22)
+    run_case(n_windows=12, H=5, R=100, n_ind=30, seed=64)
 
 
 @pytest.mark.parametrize("which", ["big", "multi"])
