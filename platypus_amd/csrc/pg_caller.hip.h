@@ -1026,23 +1026,41 @@ __device__ __forceinline__ void em_small_one(const WinDesc& W, int w, int lane,
     double fk = 1.0 / n, fr = 1.0 / n, fk_prev = fk, fr_prev = fr;           // f[k], f[r] of this lane
     const double P0 = live ? Pw[lane] : 0.0;                                  // individual 0 stays in a register
 
-    // y_k (valid in lanes with r == 0, i.e. lanes 0..n-1) and csrSum for individual i
-    auto matvec = [&](int i, double f_r, double f_k, double& y) -> double {
-        const double p = i == 0 ? P0 : (live ? Pw[(int64_t)i * nn + lane] : 0.0);
+    // y_k (valid in lanes with r == 0, i.e. lanes 0..n-1) and csrSum for the individual whose element is p
+    auto product = [&](double p, double f_r, double f_k, double& y) -> double {
         const double t = p * f_r;
         y = 0.0;
         for (int rr = 0; rr < n; ++rr) y += __shfl(t, rr * n + k);          // rows in row order
         return wave_sum((live && r == 0) ? f_k * y : 0.0);
     };
+    auto matvec = [&](int i, double f_r, double f_k, double& y) -> double {
+        return product(i == 0 ? P0 : (live ? Pw[(int64_t)i * nn + lane] : 0.0), f_r, f_k, y);
+    };
 
     while (max_change > eps && iters < max_iters) {                          // :766-768
         double acc = 0.0;
-        for (int i = 0; i < W.n_ind; ++i) {
-            if (io[i + 1] == io[i]) continue;                                // :834-835
-            double y;
-            const double s = matvec(i, fr, fk, y);
-            const double t = 2.0 * fk * y;
-            acc += s > 0.0 ? t / s : t;                                      // :852-854
+        // two individuals per pass: their sums are independent chains of lane reads, reductions and a division
+        // each, and one wavefront waits for its own instructions' latency -- side by side they overlap (four
+        // per pass were slower again); the shares are still added in individual order
+        double pa = P0, pb = (live && W.n_ind > 1) ? Pw[nn + lane] : 0.0;
+        for (int i = 0; i < W.n_ind; i += 2) {
+            const double p0 = pa, p1 = pb;
+            if (i + 2 < W.n_ind) pa = live ? Pw[(int64_t)(i + 2) * nn + lane] : 0.0;   // in flight during this pass
+            if (i + 3 < W.n_ind) pb = live ? Pw[(int64_t)(i + 3) * nn + lane] : 0.0;
+            const bool has0 = io[i + 1] != io[i];                            // :834-835
+            double y0, y1;
+            if (i + 1 < W.n_ind) {
+                const bool has1 = io[i + 2] != io[i + 1];
+                const double s0 = product(p0, fr, fk, y0);
+                const double s1 = product(p1, fr, fk, y1);
+                const double t0 = 2.0 * fk * y0, t1 = 2.0 * fk * y1;
+                if (has0) acc += s0 > 0.0 ? t0 / s0 : t0;                    // :852-854
+                if (has1) acc += s1 > 0.0 ? t1 / s1 : t1;
+            } else if (has0) {
+                const double s0 = product(p0, fr, fk, y0);
+                const double t0 = 2.0 * fk * y0;
+                acc += s0 > 0.0 ? t0 / s0 : t0;
+            }
         }
         const double nf = (0.0 + acc) / (2 * n_with_data);                   // :883
         const double ch = wave_max((live && r == 0) ? fabs(fk - nf) : 0.0);  // :885-888
