@@ -9,6 +9,10 @@ from libc.string cimport memcpy
 from libc.stdlib cimport malloc, realloc, free
 
 cdef const char* BAM_BASES = b"=ACMGRSVTWYHKDBN"
+cdef uint16_t PAIRS[256]                                 # packed byte -> its two base characters, first base in the low byte
+cdef int _pi
+for _pi in range(256):
+    PAIRS[_pi] = <uint16_t>(<unsigned char>BAM_BASES[_pi >> 4]) | (<uint16_t>(<unsigned char>BAM_BASES[_pi & 15]) << 8)
 
 
 def parseRecords(const unsigned char[::1] data, int refID, int start, int end):
@@ -116,11 +120,13 @@ def parseRecords(const unsigned char[::1] data, int refID, int start, int end):
             c += ncig
             vco[i + 1] = c
             q += 4 * ncig
-            for j in range(lseq):
-                vs[b + j] = BAM_BASES[(data[q + (j >> 1)] >> (4 * (1 - (j & 1)))) & 0xf]
+            for j in range(lseq >> 1):                      # two bases per packed byte, one 2-byte store
+                memcpy(&vs[b + 2 * j], &PAIRS[data[q + j]], 2)
+            if lseq & 1:
+                vs[b + lseq - 1] = BAM_BASES[data[q + (lseq >> 1)] >> 4]
             q += (lseq + 1) >> 1
-            for j in range(lseq):
-                vq[b + j] = data[q + j]
+            if lseq:
+                memcpy(&vq[b], &data[q], lseq)
             b += lseq
             vo[i + 1] = b
     free(starts)
