@@ -234,6 +234,7 @@ def _write_records_packed(out, coff, rid, reads, isz, mpos, bins, linear):
         i32(isz), i32(mpos))
     n = len(ends)
     voff = np.empty(n, dtype=np.int64)
+    vend = np.empty(n, dtype=np.int64)
     raw = blob.tobytes()
     cuts, i = [0], 0
     while i < n:
@@ -254,8 +255,12 @@ def _write_records_packed(out, coff, rid, reads, isz, mpos, bins, linear):
             i, j = cuts[k], cuts[k + 1]
             out.write(blk)
             voff[i:j] = (coff << 16) | (rec_off[i:j] - rec_off[i])
+            vend[i:j] = voff[i:j] + (rec_off[i + 1:j + 1] - rec_off[i:j])
             coff += len(blk)
-    vend = voff + (rec_off[1:] - rec_off[:-1])
+            # a reader that has consumed a whole block stands at the start of the next one (bgzf_read,
+            # c/samtools/bgzf.c), and bam_iter_read asserts that a chunk ends where the reader stands
+            # (c/samtools/bam_index.c:680): the end of a block's last record is the next block's offset 0
+            vend[j - 1] = coff << 16
     order = np.argsort(rbin, kind="stable")
     sb = rbin[order]
     cuts = np.flatnonzero(np.diff(sb)) + 1
@@ -317,7 +322,20 @@ def write_bam(path, refs, reads, sample="sample", names=None):
     block, coff = bytearray(head), 0
     bins, linear = {}, {}
 
+    last_chunk = None                                    # the [begin, end] pair of the record written last
+
     def flush():
+        nonlocal block, coff
+        at_end = (coff << 16) | len(block) if len(block) <= 0xff00 else None
+        try:
+            _flush()
+        finally:
+            # the end of a block's last record is written as the next block's offset 0, as a reader
+            # that has consumed the block reports it (see _write_records_packed)
+            if last_chunk is not None and at_end is not None and last_chunk[1] == at_end:
+                last_chunk[1] = coff << 16
+
+    def _flush():
         nonlocal block, coff
         while block:
             chunk, block = bytes(block[:0xff00]), block[0xff00:]
@@ -353,7 +371,8 @@ def write_bam(path, refs, reads, sample="sample", names=None):
         voff = (coff << 16) | len(block)
         block += struct.pack("<i", len(rec)) + rec
         vend = (coff << 16) | len(block)
-        bins.setdefault(b, []).append([voff, vend])
+        last_chunk = [voff, vend]
+        bins.setdefault(b, []).append(last_chunk)
         for w in range(pos >> 14, (max(end, pos + 1) - 1 >> 14) + 1):
             if w not in linear:
                 linear[w] = voff

@@ -57,9 +57,11 @@ def parseRecords(const unsigned char[::1] data, int refID, int start, int end):
                 for k in range(ncig):
                     memcpy(&cw, &data[q + 4 * k], 4)
                     op = cw & 0xf
-                    if op == 0 or op == 2 or op == 3 or op == 7 or op == 8:
+                    if op == 0 or op == 2 or op == 3:         # what bam_calend counts (c/samtools/bam.c:17-27)
                         rend += cw >> 4
-                if rend > start or (rend == pos and pos >= start):
+                if ncig == 0:                               # is_overlap, c/samtools/bam_index.c:556-561
+                    rend = pos + 1
+                if rend > start:
                     if nrec == cap:
                         grown = <Py_ssize_t*>realloc(starts, 2 * cap * sizeof(Py_ssize_t))
                         if grown == NULL:
