@@ -335,6 +335,60 @@ int pg_valu_int16_peak(pg_ctx *ctx, double *ops_per_second);
  */
 int pg_valu_vop2_rate(pg_ctx *ctx, double *lane_instructions_per_second);
 
+/* ------------------------------------------------------------------------
+ * BGZF inflation on the device.
+ *
+ * Replaces, for the stretch of a BAM file a region fetch reads, what the
+ * reference gets from its vendored samtools: bgzf_read_block / inflate_block
+ * (platypus/c/samtools/bgzf.c), reached through bam_read1 from
+ * platypus/samtoolsWrapper.pyx (Samfile.fetch, IteratorRow).  One lane
+ * inflates one BGZF block; the host finds the block boundaries only.
+ *
+ * An inflater is independent of any pg_ctx (own stream, device buffers and one
+ * page-locked output buffer); one thread at a time may use it, several may
+ * exist per process and device.
+ * ------------------------------------------------------------------------ */
+typedef struct pg_inflater pg_inflater;
+int pg_inflater_create(int device_ordinal, pg_inflater **out);
+int pg_inflater_destroy(pg_inflater *h);
+/* message of the last failed call on h (of the last failed create for NULL) */
+const char *pg_inflater_error(const pg_inflater *h);
+/* BGZF blocks per wavefront, 16 (default), 32 or 64: measurements */
+int pg_inflater_set_lanes(pg_inflater *h, int lanes);
+/* device time of the last call's kernel, milliseconds */
+int pg_inflater_last_ms(pg_inflater *h, float *ms);
+
+/*
+ * A page-locked buffer of at least `bytes` bytes, owned by the inflater, for
+ * the caller to read file bytes into: pg_bgzf_inflate copies from it to the
+ * device without the runtime's staging copy (which callers on several threads
+ * would contend for).  Grow-only; growing keeps the content; valid until the
+ * next call of this function with a larger size, or the inflater's end.
+ */
+int pg_inflater_input(pg_inflater *h, size_t bytes, void **buf);
+
+/*
+ * Host only: the complete BGZF blocks at the start of raw[0, n_raw) -- bytes
+ * they occupy, bytes they inflate to (sum of ISIZE), their number (n_blocks
+ * may be NULL).  PG_ERR_UNSUPPORTED for bytes that are not a BGZF block
+ * (check_header, c/samtools/bgzf.c).
+ */
+int pg_bgzf_scan(const void *raw, size_t n_raw, size_t *consumed, size_t *total_out, int *n_blocks);
+
+/*
+ * Inflates every complete BGZF block at the start of raw[0, n_raw), one after
+ * the other, behind a copy of prefix[0, n_prefix) (what the caller had left
+ * over from the previous call; it may point into the buffer the previous call
+ * returned).  *out is the inflater's own page-locked buffer, valid until the
+ * next call on h or its destruction; *n_out = n_prefix + inflated bytes;
+ * *consumed = bytes of raw the complete blocks occupy (a trailing incomplete
+ * block is left to the caller).  A block whose deflate stream is corrupt or
+ * does not produce ISIZE bytes: PG_ERR_UNSUPPORTED (the CRC is not checked,
+ * as in the reference's inflate_block).  At most 1 GiB in, 3 GiB out per call.
+ */
+int pg_bgzf_inflate(pg_inflater *h, const void *raw, size_t n_raw, const void *prefix, size_t n_prefix,
+                    void **out, size_t *n_out, size_t *consumed);
+
 #ifdef __cplusplus
 }
 #endif

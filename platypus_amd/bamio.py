@@ -38,9 +38,41 @@ def _read_block(f):
     return zlib.decompress(body[:-8], -15), bsize + 1
 
 
+class InflaterPool(object):
+    """A few device inflaters (cbam.DeviceInflater) shared by the threads that read BAM files: a fetch borrows one
+    for its duration.  Few on purpose: every inflater has a stream of its own, a call takes tens of milliseconds
+    whatever it inflates, and a device serves only so many queues at once before it takes turns between them."""
+
+    _shared = {}
+
+    @classmethod
+    def shared(cls, device=0, size=4):
+        """the process's pool for a device: made once and kept (a run after the first finds its inflaters there;
+        inflaters are not taken down while others are at work)"""
+        key = (device, size)
+        if key not in cls._shared:
+            cls._shared[key] = cls(device, size)
+        return cls._shared[key]
+
+    def __init__(self, device=0, size=4):
+        import queue
+        self._free = queue.LifoQueue()
+        for _ in range(max(1, size)):
+            self._free.put(cbam.DeviceInflater(device))
+
+    def acquire(self):
+        return self._free.get()
+
+    def release(self, inflater):
+        self._free.put(inflater)
+
+
 class BamReader(object):
-    def __init__(self, fileName, indexName=None):
+    def __init__(self, fileName, indexName=None, inflater=None):
+        """inflater: a cbam.DeviceInflater, or an InflaterPool to borrow one from per fetch, for the record stream
+        (BGZF blocks inflated on the GPU); without one the blocks are inflated by the host library"""
         self.fileName = fileName
+        self._inflater = inflater
         self.f = open(fileName, "rb")
         data, pos = b"", 0
         # header: may span blocks
@@ -106,6 +138,15 @@ class BamReader(object):
 
     def fetch(self, chrom, start, end):
         """packed records of `chrom` overlapping [start, end) (0-based), in position order"""
+        pool = self._inflater if isinstance(self._inflater, InflaterPool) else None
+        inflater = pool.acquire() if pool is not None else self._inflater
+        try:
+            return self._fetch(chrom, start, end, inflater)
+        finally:
+            if pool is not None:
+                pool.release(inflater)
+
+    def _fetch(self, chrom, start, end, inflater):
         chrom = chrom if isinstance(chrom, bytes) else chrom.encode()
         if chrom not in self.refs:
             raise KeyError("no reference %r in %s" % (chrom, self.fileName))
@@ -130,7 +171,10 @@ class BamReader(object):
             self.f.seek(voff >> 16)
             tail = _EMPTY
             skip = voff & 0xffff                          # the first record starts inside the first block
-        parts, raw = [], b""
+        parts = []
+        if inflater is not None:
+            return self._fetch_device(rid, start, end, inflater, voff, lin if voff is not None else None, tail, skip)
+        raw = b""
         while True:
             chunk = self.f.read(4 << 20)
             raw = raw + chunk if raw else chunk
@@ -148,6 +192,39 @@ class BamReader(object):
                 parts.append(arrays)
             tail = data[used:]
             if done or not chunk:
+                break
+        return _concat(parts)
+
+    def _fetch_device(self, rid, start, end, inflater, voff, lin, tail, skip):
+        """the loop of _fetch with the blocks inflated on the GPU.  File bytes are read straight into the inflater's
+        page-locked input buffer.  With an index the first read takes the stretch up to where the index says the
+        window after `end` begins: one inflation call for the whole stretch (a call takes about as long for a
+        thousand blocks as for one); smaller reads follow until a record beyond the region has been met."""
+        parts = []
+        want = 4 << 20
+        if voff is not None:
+            w = min((max(end, 0) >> 14) + 1, len(lin) - 1)
+            stop = int(np.max(lin[:w + 1])) >> 16
+            want = min(max(want, stop - (voff >> 16) + (1 << 16)), 512 << 20)
+        left = 0                                          # bytes of an incomplete block at the start of the input buffer
+        while True:
+            buf = inflater.inputBuffer(left + want)
+            got = self.f.readinto(memoryview(buf)[left:])
+            data, eaten = inflater.inflateBlocks(buf[:left + got], tail)
+            left = left + got - eaten
+            if left:
+                buf[:left] = buf[eaten:eaten + left].copy()
+            want = 4 << 20
+            if skip:
+                if len(data) < skip and got:
+                    tail = data
+                    continue
+                data, skip = data[skip:], 0
+            arrays, used, done = cbam.parseRecords(data, rid, start, end)
+            if len(arrays["pos"]):
+                parts.append(arrays)
+            tail = data[used:]
+            if done or not got:
                 break
         return _concat(parts)
 
@@ -183,15 +260,16 @@ def drop_before(arrays, start):
     return out
 
 
-def fetch_split(path, chrom, start, end, parts):
+def fetch_split(path, chrom, start, end, parts, inflater=None):
     """BamReader.fetch(chrom, start, end) with the stretch cut into `parts` pieces that are read, inflated and decoded
-    side by side (every piece on a thread and a file handle of its own; a piece after the first keeps the records
-    that start inside it, so every record is returned once, in position order)."""
+    side by side (every piece on a thread and a file handle of its own; `inflater`: an InflaterPool the pieces borrow
+    from; a piece after the first keeps the records that start inside it, so every record is returned once, in position
+    order)."""
     from concurrent.futures import ThreadPoolExecutor
     edges = [start + (end - start) * k // parts for k in range(parts + 1)]
 
     def piece(k):
-        r = BamReader(path)
+        r = BamReader(path, inflater=inflater)
         try:
             a = r.fetch(chrom, edges[k], edges[k + 1])
         finally:

@@ -397,3 +397,55 @@ def inflateBlocks(const unsigned char[::1] raw, const unsigned char[::1] prefix)
     if bad:
         raise IOError("corrupt BGZF block" if bad == 2 else "zlib could not be initialised")
     return out, consumed
+
+
+cdef extern from "platgpu.h":
+    ctypedef struct pg_inflater:
+        pass
+    int pg_inflater_create(int device_ordinal, pg_inflater** out) nogil
+    int pg_inflater_destroy(pg_inflater* h) nogil
+    const char* pg_inflater_error(const pg_inflater* h) nogil
+    int pg_inflater_input(pg_inflater* h, size_t nbytes, void** buf) nogil
+    int pg_bgzf_inflate(pg_inflater* h, const void* raw, size_t n_raw, const void* prefix, size_t n_prefix,
+                        void** out, size_t* n_out, size_t* consumed) nogil
+
+
+cdef class DeviceInflater:
+    """inflateBlocks on the GPU (pg_bgzf_inflate: one lane per BGZF block).  The array a call returns is a
+    view of the inflater's page-locked buffer and is valid until the next call; one thread at a time."""
+    cdef pg_inflater* h
+
+    def __cinit__(self, int device=0):
+        self.h = NULL
+        if pg_inflater_create(device, &self.h) != 0:
+            raise RuntimeError("pg_inflater_create: " + pg_inflater_error(NULL).decode())
+
+    def __dealloc__(self):
+        if self.h != NULL:
+            pg_inflater_destroy(self.h)
+            self.h = NULL
+
+    def inputBuffer(self, size_t n):
+        """uint8 view (n bytes) of the inflater's page-locked input buffer: file bytes read into it go to the
+        device without a staging copy.  Growing keeps the content; earlier views are invalid after a growth."""
+        cdef void* buf = NULL
+        if pg_inflater_input(self.h, n, &buf) != 0:
+            raise MemoryError(pg_inflater_error(self.h).decode())
+        if n == 0:
+            return np.zeros(0, dtype=np.uint8)
+        return np.asarray(<unsigned char[:n]> (<unsigned char*>buf))
+
+    def inflateBlocks(self, const unsigned char[::1] raw, const unsigned char[::1] prefix):
+        cdef void* out = NULL
+        cdef size_t n_out = 0, eaten = 0
+        cdef const unsigned char* rp = &raw[0] if raw.shape[0] else NULL
+        cdef const unsigned char* pp = &prefix[0] if prefix.shape[0] else NULL
+        cdef size_t nr = raw.shape[0], npre = prefix.shape[0]
+        cdef int rc
+        with nogil:
+            rc = pg_bgzf_inflate(self.h, rp, nr, pp, npre, &out, &n_out, &eaten)
+        if rc != 0:
+            raise IOError(pg_inflater_error(self.h).decode())
+        if n_out == 0:
+            return np.zeros(0, dtype=np.uint8), eaten
+        return np.asarray(<unsigned char[:n_out]> (<unsigned char*>out)), eaten

@@ -13,11 +13,14 @@
 #include <type_traits>
 #include <vector>
 
+#include <unistd.h>
+
 #include "../../include/platgpu.h"
 #include "pg_kernels.hip.h"
 #include "pg_align.hip.h"
 #include "pg_prep.hip.h"
 #include "pg_caller.hip.h"
+#include "pg_inflate.hip.h"
 
 namespace {
 
@@ -389,7 +392,11 @@ int pg_ctx_create(int device_ordinal, int max_read_len, pg_ctx** out) {
     c->device = device_ordinal;
     c->max_read_len = max_read_len;
     c->table = kDefaultTable;
-    if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
+    // the context's stream is a high-priority one: it gets a hardware queue that the (low-priority) streams of the
+    // BGZF inflaters do not share, so its short kernels never queue behind their long ones
+    int prio_low = 0, prio_high = 0;
+    if (hipSetDevice(device_ordinal) == hipSuccess) (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+    if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithPriority(&c->stream, hipStreamDefault, prio_high) != hipSuccess) {
         delete c;
         return fail(nullptr, PG_ERR_HIP, "cannot create a stream on device %d", device_ordinal);
     }
@@ -1198,6 +1205,252 @@ int pg_valu_int16_peak(pg_ctx* c, double* ops_per_second) {
 int pg_valu_vop2_rate(pg_ctx* c, double* lane_instructions_per_second) {
     if (!c || !lane_instructions_per_second) return PG_ERR_INVALID;
     return time_rate_probe(c, pg::k_vop2_rate, lane_instructions_per_second);
+}
+
+}  // extern "C"
+
+// ---- BGZF inflation (pg_inflate.hip.h) ----------------------------------------------------
+// An inflater is independent of any pg_ctx: a stream, grow-only device buffers and one page-locked output
+// buffer of its own, so that helper threads that read BAM files can each keep one beside the thread that calls
+// variants.  One thread at a time per inflater.
+struct pg_inflater {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;                    // blocking-sync event: the waiting thread sleeps
+    DevBuf<unsigned char> d_raw, d_out;
+    DevBuf<pg::InflBlock> d_blocks;
+    DevBuf<int32_t> d_status;
+    unsigned char* h_out = nullptr;               // page-locked; what pg_bgzf_inflate hands out
+    size_t h_out_cap = 0;
+    unsigned char* h_in = nullptr;                // page-locked; what pg_inflater_input hands out
+    size_t h_in_cap = 0;
+    std::vector<pg::InflBlock> blocks;
+    int32_t* h_status = nullptr;                  // page-locked as well: a copy into pageable memory would make the call spin
+    size_t h_status_cap = 0;
+    int lanes = 16;                               // BGZF blocks per wavefront (16, 32 or 64)
+    float last_ms = 0;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    std::string err;
+};
+
+namespace {
+int ifail(pg_inflater* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_create_error = buf;
+    return code;
+}
+#define PG_IHIP(h, call)                                                                    \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return ifail((h), PG_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+// Block boundaries of the complete BGZF blocks at the start of raw (header layout: c/samtools/bgzf.c,
+// check_header and the BSIZE field).  Returns 0, or -1 for bytes that are not a BGZF block.
+int bgzf_scan(const unsigned char* raw, size_t n, std::vector<pg::InflBlock>* blocks, size_t* consumed, size_t* total) {
+    size_t p = 0, out = 0;
+    while (p + 18 <= n) {
+        if (raw[p] != 0x1f || raw[p + 1] != 0x8b || raw[p + 2] != 8 || !(raw[p + 3] & 4)) return -1;
+        const size_t xlen = raw[p + 10] | (raw[p + 11] << 8);
+        if (p + 12 + xlen > n) break;
+        long bsize = -1;
+        size_t k = p + 12;
+        while (k + 4 <= p + 12 + xlen) {
+            const size_t slen = raw[k + 2] | (raw[k + 3] << 8);
+            if (raw[k] == 66 && raw[k + 1] == 67 && slen == 2 && k + 6 <= p + 12 + xlen) bsize = raw[k + 4] | (raw[k + 5] << 8);
+            k += 4 + slen;
+        }
+        if (bsize < 0 || (size_t)bsize + 1 < 12 + xlen + 8) return -1;
+        if (p + bsize + 1 > n) break;
+        uint32_t isize;
+        memcpy(&isize, raw + p + bsize + 1 - 4, 4);
+        if (isize > 65536) return -1;
+        if (blocks) {
+            pg::InflBlock b;
+            b.in_off = (uint32_t)(p + 12 + xlen);
+            b.in_len = (uint32_t)(bsize + 1 - 12 - xlen - 8);
+            b.out_off = (uint32_t)out;
+            b.out_len = isize;
+            blocks->push_back(b);
+        }
+        out += isize;
+        p += bsize + 1;
+    }
+    *consumed = p;
+    *total = out;
+    return 0;
+}
+
+template <int AL>
+hipError_t launch_inflate(pg_inflater* h, int n_blocks) {
+    const size_t lds = (size_t)pg::IT_U16 * 2 * AL;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_bgzf_inflate<AL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(pg::k_bgzf_inflate<AL>, dim3((n_blocks + AL - 1) / AL), dim3(64), lds, h->stream, h->d_raw.p, h->d_blocks.p,
+                       n_blocks, h->d_out.p, h->d_status.p);
+    return hipGetLastError();
+}
+}  // namespace
+
+extern "C" {
+
+int pg_inflater_create(int device_ordinal, pg_inflater** out) {
+    if (!out) return ifail(nullptr, PG_ERR_INVALID, "pg_inflater_create: out is NULL");
+    *out = nullptr;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || device_ordinal < 0 || device_ordinal >= n_dev)
+        return ifail(nullptr, PG_ERR_NO_DEVICE, "no HIP device %d", device_ordinal);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_ordinal) != hipSuccess || strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return ifail(nullptr, PG_ERR_NO_DEVICE, "device %d is not gfx950", device_ordinal);
+    pg_inflater* h = new pg_inflater();
+    h->device = device_ordinal;
+    hipError_t e = hipSetDevice(device_ordinal);
+    int prio_low = 0, prio_high = 0;
+    if (e == hipSuccess) e = hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_low);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->done, hipEventBlockingSync | hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreate(&h->t0);
+    if (e == hipSuccess) e = hipEventCreate(&h->t1);
+    if (e != hipSuccess) {
+        ifail(nullptr, PG_ERR_HIP, "pg_inflater_create: %s", hipGetErrorString(e));
+        delete h;
+        return PG_ERR_HIP;
+    }
+    *out = h;
+    return PG_OK;
+}
+
+int pg_inflater_destroy(pg_inflater* h) {
+    if (!h) return PG_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    h->d_raw.release(); h->d_out.release(); h->d_blocks.release(); h->d_status.release();
+    if (h->h_out) (void)hipHostFree(h->h_out);
+    if (h->h_status) (void)hipHostFree(h->h_status);
+    if (h->h_in) (void)hipHostFree(h->h_in);
+    if (h->done) (void)hipEventDestroy(h->done);
+    if (h->t0) (void)hipEventDestroy(h->t0);
+    if (h->t1) (void)hipEventDestroy(h->t1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return PG_OK;
+}
+
+const char* pg_inflater_error(const pg_inflater* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int pg_inflater_input(pg_inflater* h, size_t bytes, void** buf) {
+    if (!h || !buf) return PG_ERR_INVALID;
+    if (bytes > h->h_in_cap) {
+        PG_IHIP(h, hipSetDevice(h->device));
+        unsigned char* fresh = nullptr;
+        const size_t cap = bytes + bytes / 4 + 4096;
+        PG_IHIP(h, hipHostMalloc(reinterpret_cast<void**>(&fresh), cap, hipHostMallocDefault));
+        if (h->h_in) {
+            memcpy(fresh, h->h_in, h->h_in_cap);
+            (void)hipHostFree(h->h_in);
+        }
+        h->h_in = fresh;
+        h->h_in_cap = cap;
+    }
+    *buf = h->h_in;
+    return PG_OK;
+}
+
+int pg_inflater_set_lanes(pg_inflater* h, int lanes) {
+    if (!h || (lanes != 16 && lanes != 32 && lanes != 64)) return PG_ERR_INVALID;
+    h->lanes = lanes;
+    return PG_OK;
+}
+
+int pg_inflater_last_ms(pg_inflater* h, float* ms) {
+    if (!h || !ms) return PG_ERR_INVALID;
+    *ms = h->last_ms;
+    return PG_OK;
+}
+
+int pg_bgzf_scan(const void* raw, size_t n_raw, size_t* consumed, size_t* total_out, int* n_blocks) {
+    if ((!raw && n_raw) || !consumed || !total_out) return PG_ERR_INVALID;
+    std::vector<pg::InflBlock> blocks;
+    if (bgzf_scan(static_cast<const unsigned char*>(raw), n_raw, n_blocks ? &blocks : nullptr, consumed, total_out) != 0)
+        return PG_ERR_UNSUPPORTED;
+    if (n_blocks) *n_blocks = (int)blocks.size();
+    return PG_OK;
+}
+
+int pg_bgzf_inflate(pg_inflater* h, const void* raw_, size_t n_raw, const void* prefix, size_t n_prefix,
+                    void** out, size_t* n_out, size_t* consumed) {
+    if (!h) return PG_ERR_INVALID;
+    if ((!raw_ && n_raw) || (!prefix && n_prefix) || !out || !n_out || !consumed) return ifail(h, PG_ERR_INVALID, "pg_bgzf_inflate: NULL argument");
+    if (n_raw > (size_t)1 << 30) return ifail(h, PG_ERR_INVALID, "pg_bgzf_inflate: at most 1 GiB of compressed bytes per call");
+    const unsigned char* raw = static_cast<const unsigned char*>(raw_);
+    h->blocks.clear();
+    size_t eaten = 0, total = 0;
+    if (bgzf_scan(raw, n_raw, &h->blocks, &eaten, &total) != 0) return ifail(h, PG_ERR_UNSUPPORTED, "not a BGZF block");
+    if (total > (size_t)3 << 30) return ifail(h, PG_ERR_INVALID, "pg_bgzf_inflate: more than 3 GiB of output in one call");
+    PG_IHIP(h, hipSetDevice(h->device));
+    const size_t need = n_prefix + total;
+    if (need > h->h_out_cap) {
+        // the prefix may lie in the buffer that is about to be replaced
+        unsigned char* fresh = nullptr;
+        const size_t cap = need + need / 4 + 4096;
+        PG_IHIP(h, hipHostMalloc(reinterpret_cast<void**>(&fresh), cap, hipHostMallocDefault));
+        if (n_prefix) memcpy(fresh, prefix, n_prefix);
+        if (h->h_out) (void)hipHostFree(h->h_out);
+        h->h_out = fresh;
+        h->h_out_cap = cap;
+    } else if (n_prefix && prefix != h->h_out) {
+        memmove(h->h_out, prefix, n_prefix);
+    }
+    *out = h->h_out;
+    *n_out = need;
+    *consumed = eaten;
+    h->last_ms = 0;
+    const int nb = (int)h->blocks.size();
+    if (nb == 0 || total == 0) return PG_OK;
+    PG_IHIP(h, h->d_raw.reserve(eaten + 64));
+    PG_IHIP(h, h->d_out.reserve(total + 64));
+    PG_IHIP(h, h->d_blocks.reserve(nb));
+    PG_IHIP(h, h->d_status.reserve(nb));
+    if ((size_t)nb > h->h_status_cap) {
+        if (h->h_status) (void)hipHostFree(h->h_status);
+        h->h_status = nullptr;
+        h->h_status_cap = 0;
+        PG_IHIP(h, hipHostMalloc(reinterpret_cast<void**>(&h->h_status), ((size_t)nb + 1024) * sizeof(int32_t), hipHostMallocDefault));
+        h->h_status_cap = (size_t)nb + 1024;
+    }
+    PG_IHIP(h, hipMemcpyAsync(h->d_raw.p, raw, eaten, hipMemcpyHostToDevice, h->stream));
+    PG_IHIP(h, hipMemcpyAsync(h->d_blocks.p, h->blocks.data(), (size_t)nb * sizeof(pg::InflBlock), hipMemcpyHostToDevice, h->stream));
+    PG_IHIP(h, hipEventRecord(h->t0, h->stream));
+    if (h->lanes == 16) PG_IHIP(h, launch_inflate<16>(h, nb));
+    else if (h->lanes == 32) PG_IHIP(h, launch_inflate<32>(h, nb));
+    else PG_IHIP(h, launch_inflate<64>(h, nb));
+    PG_IHIP(h, hipEventRecord(h->t1, h->stream));
+    PG_IHIP(h, hipEventRecord(h->done, h->stream));
+    // The kernel runs for tens of milliseconds whatever the number of blocks.  The calling thread sleeps in short
+    // steps instead of spinning on the event (helper threads share the host's cores with the thread that calls
+    // variants), and the copies back are queued only once the kernel has ended: a copy that waits for a kernel
+    // inside a copy engine's queue holds up the copies of every other stream behind it.
+    usleep(15000);
+    for (;;) {
+        const hipError_t q = hipEventQuery(h->done);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) return ifail(h, PG_ERR_HIP, "hipEventQuery failed: %s", hipGetErrorString(q));
+        usleep(1000);
+    }
+    PG_IHIP(h, hipMemcpyAsync(h->h_out + n_prefix, h->d_out.p, total, hipMemcpyDeviceToHost, h->stream));
+    PG_IHIP(h, hipMemcpyAsync(h->h_status, h->d_status.p, (size_t)nb * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    PG_IHIP(h, hipStreamSynchronize(h->stream));
+    (void)hipEventElapsedTime(&h->last_ms, h->t0, h->t1);
+    for (int b = 0; b < nb; ++b)
+        if (h->h_status[b] != pg::INF_OK)
+            return ifail(h, PG_ERR_UNSUPPORTED, "corrupt BGZF block %d of the stretch (deflate error %d)", b, h->h_status[b]);
+    return PG_OK;
 }
 
 }  // extern "C"

@@ -53,6 +53,15 @@ SYMBOLS = {
     "pg_variant_posteriors": (C.c_int, [C.c_void_p, C.c_int, _i32p, C.c_void_p, _f64p, _f64p]),
     "pg_valu_int16_peak": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "pg_valu_vop2_rate": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "pg_inflater_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "pg_inflater_destroy": (C.c_int, [C.c_void_p]),
+    "pg_inflater_error": (C.c_char_p, [C.c_void_p]),
+    "pg_inflater_set_lanes": (C.c_int, [C.c_void_p, C.c_int]),
+    "pg_inflater_last_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "pg_inflater_input": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "pg_bgzf_scan": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
+    "pg_bgzf_inflate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p),
+                                  C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
 }
 
 
@@ -271,3 +280,66 @@ class AlignContext(object):
         out = np.empty(len(vw), dtype=np.float64)
         self._check(LIB.pg_variant_posteriors(self._h, len(vw), _ptr(vw), _ptr(m), _ptr(pr), _ptr(out)))
         return out
+
+
+def bgzf_scan(raw):
+    """(bytes the complete BGZF blocks at the start of `raw` occupy, bytes they inflate to, their number); host only"""
+    raw = np.ascontiguousarray(np.frombuffer(raw, dtype=np.uint8))
+    eaten, total, nb = C.c_size_t(0), C.c_size_t(0), C.c_int(0)
+    rc = LIB.pg_bgzf_scan(_ptr(raw), raw.size, C.byref(eaten), C.byref(total), C.byref(nb))
+    if rc != PG_OK:
+        raise PlatGpuError(rc, "not a BGZF block")
+    return eaten.value, total.value, nb.value
+
+
+class Inflater(object):
+    """BGZF inflation on the device (pg_inflater_*, pg_bgzf_inflate)."""
+
+    def __init__(self, device=0):
+        h = C.c_void_p()
+        rc = LIB.pg_inflater_create(device, C.byref(h))
+        if rc != PG_OK:
+            raise PlatGpuError(rc, (LIB.pg_inflater_error(None) or b"").decode())
+        self._h = h
+
+    def close(self):
+        if self._h:
+            LIB.pg_inflater_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_lanes(self, lanes):
+        if LIB.pg_inflater_set_lanes(self._h, lanes) != PG_OK:
+            raise ValueError("lanes must be 16, 32 or 64")
+
+    def last_ms(self):
+        ms = C.c_float(0)
+        LIB.pg_inflater_last_ms(self._h, C.byref(ms))
+        return ms.value
+
+    def input_buffer(self, n):
+        """uint8 view of the inflater's page-locked input buffer, n bytes"""
+        buf = C.c_void_p()
+        rc = LIB.pg_inflater_input(self._h, n, C.byref(buf))
+        if rc != PG_OK:
+            raise PlatGpuError(rc, (LIB.pg_inflater_error(self._h) or b"").decode())
+        return np.frombuffer((C.c_uint8 * n).from_address(buf.value), dtype=np.uint8) if n else np.zeros(0, np.uint8)
+
+    def inflate(self, raw, prefix=b""):
+        """(uint8 array: prefix + the inflated complete blocks at the start of raw, bytes of raw consumed).  The array
+        is a view of the inflater's own page-locked buffer: valid until the next call."""
+        raw = np.ascontiguousarray(np.frombuffer(raw, dtype=np.uint8))
+        prefix = np.ascontiguousarray(np.frombuffer(prefix, dtype=np.uint8))
+        out, n_out, eaten = C.c_void_p(), C.c_size_t(0), C.c_size_t(0)
+        rc = LIB.pg_bgzf_inflate(self._h, _ptr(raw), raw.size, _ptr(prefix), prefix.size, C.byref(out), C.byref(n_out), C.byref(eaten))
+        if rc != PG_OK:
+            raise PlatGpuError(rc, (LIB.pg_inflater_error(self._h) or b"").decode())
+        if n_out.value == 0:
+            return np.zeros(0, dtype=np.uint8), eaten.value
+        buf = (C.c_uint8 * n_out.value).from_address(out.value)
+        return np.frombuffer(buf, dtype=np.uint8), eaten.value

@@ -68,18 +68,21 @@ def call_chunks(chunks, args, tmpdir):
 
     local = threading.local()
     opened = []
+    inflaters = None                                      # --inflate device: BGZF blocks are inflated on the GPU
+    if args.inflate == "device":
+        inflaters = bamio.InflaterPool.shared(int(os.environ.get("PLATGPU_DEVICE", "0")), args.inflaters)
 
     def load(unit, split=1):                              # fetch, inflate, decode, filter and trim: all outside the lock
         (chrom, _, _), s, e = unit
         if not hasattr(local, "readers"):                 # a file handle per helper thread
-            local.readers = [bamio.BamReader(b) for b in args.bamFiles.split(",")]
+            local.readers = [bamio.BamReader(b, inflater=inflaters) for b in args.bamFiles.split(",")]
             opened.extend(local.readers)
         bufs = []
         for r in local.readers:
             t0 = time.perf_counter()
             try:
                 # the run's first stretch is read in pieces side by side: nothing can be called before it is there
-                reads = r.fetch(chrom, s, e) if split <= 1 else bamio.fetch_split(r.fileName, chrom, s, e, split)
+                reads = r.fetch(chrom, s, e) if split <= 1 else bamio.fetch_split(r.fileName, chrom, s, e, split, inflaters)
             except KeyError:                              # this BAM has no such sequence: no reads from it
                 reads = bamio._concat([])
             reads["chrom"] = chrom.encode()
@@ -176,6 +179,14 @@ def main(argv=None):
                     help="buffers prepared ahead of the one being called, each on a helper thread of its own "
                          "(default: 12 for a single host process, 6 per process otherwise); a shared pool of piece readers "
                          "under a few buffer threads was measured and is slower")
+    ap.add_argument("--inflate", choices=["auto", "device", "host"], default="auto",
+                    help="where the BGZF blocks of the BAM files are inflated: on the GPU (one lane per block; a third fewer "
+                         "host core-seconds per Mb) or by the host library on the helper threads.  auto: on the GPU when one "
+                         "host process drives a GPU, by the host library when several share one (they are there to use the "
+                         "host's spare cores, and their many inflater streams would take turns on the device)")
+    ap.add_argument("--inflaters", type=int, default=None,
+                    help="device inflaters of a host process, shared by its helper threads (default: 4 for a single process, "
+                         "2 per process otherwise)")
     ap.add_argument("--nCPU", type=int, default=None,
                     help="the reference's option: taken as the total number of host processes when --workersPerGPU is not given")
     ap.add_argument("--labels", default=None, help="regular expression that extracts a sample name from a BAM path")
@@ -208,6 +219,10 @@ def main(argv=None):
     n_workers = max(1, args.nGPU) * max(1, args.workersPerGPU)
     if args.readAhead is None:
         args.readAhead = 12 if n_workers == 1 else 6
+    if args.inflaters is None:
+        args.inflaters = 4 if n_workers == 1 else 2
+    if args.inflate == "auto":
+        args.inflate = "device" if max(1, args.workersPerGPU) == 1 else "host"
     weights = None
     if n_workers > 1:                                       # longest first by the reads a chunk holds, as far as the
         from platypus_amd import bamio                      # BAM indexes tell (compressed bytes), else by length

@@ -19,6 +19,9 @@ from platypus_amd import bamio, runner, simulate  # noqa: E402
 
 
 def main():
+    if os.environ.get("TF_DUMP_AFTER"):                         # stacks of all threads if the run is still going then
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["TF_DUMP_AFTER"]), exit=True)
     kb = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
     cov = int(sys.argv[2]) if len(sys.argv) > 2 else 30
     work = sys.argv[3] if len(sys.argv) > 3 else tempfile.mkdtemp(prefix="pa_files_")
