@@ -129,16 +129,18 @@ def end_to_end_leg(kb=2000, coverage=30, copies=32):
         for line in open(out):
             if not line.startswith("#"):
                 called.add(int(line.split("\t")[1]) - 1)
-        out_d = dict(by_mode["device"])                      # the runner's default: BGZF blocks inflated on the GPU
-        out_d["bgzf_inflated_by_host"] = by_mode["host"]
+        # top level: what the runner does by itself (--inflate auto): one process inflates the BGZF blocks on the GPU,
+        # several processes that share a GPU leave it to the host library
+        out_d = {k: by_mode["host" if k.endswith("8_host_processes") else "device"][k] for k in by_mode["device"]}
+        out_d["by_inflate_mode"] = by_mode
         out_d.update({
                 "genome_kb": kb * copies, "simulated_kb": kb, "repeats": copies, "coverage": coverage,
                 "read_length": 150, "paired": True,
                 "reads": int(len(reads["pos"])), "bam_mb": os.path.getsize(bam) / 1e6, "vcf_records": len(called),
                 "planted_variants": len(truth), "planted_found": sum(p in called for p, r, a, g in truth),
                 "processes": 1, "what": "simulated BAM + .bai and FASTA + .fai -> VCF, platypus_amd.runner in a process of its own, "
-                                        "start-up included; BGZF blocks inflated on the GPU (bgzf_inflated_by_host: the same "
-                                        "runs with --inflate host)"})
+                                        "start-up included; BGZF blocks inflated on the GPU by the single process, by the host "
+                                        "library in the eight (runner --inflate auto); by_inflate_mode: every combination"})
         return out_d
     finally:
         shutil.rmtree(work, ignore_errors=True)
