@@ -353,7 +353,7 @@ int pg_inflater_create(int device_ordinal, pg_inflater **out);
 int pg_inflater_destroy(pg_inflater *h);
 /* message of the last failed call on h (of the last failed create for NULL) */
 const char *pg_inflater_error(const pg_inflater *h);
-/* BGZF blocks per wavefront, 16 (default), 32 or 64: measurements */
+/* BGZF blocks per wavefront, 8 (default), 16 or 32: measurements */
 int pg_inflater_set_lanes(pg_inflater *h, int lanes);
 /* device time of the last call's kernel, milliseconds */
 int pg_inflater_last_ms(pg_inflater *h, float *ms);

@@ -532,6 +532,7 @@ struct EmState {
     int32_t* done;      // per window
     int32_t* active;    // one counter
     int32_t* arrived;   // per window: workgroups of the running step that have stored their share
+    double* csr;        // per (window, individual): csrSum of the individual's last step (k_em_calls divides by it)
     const int64_t* share_base;   // per window: offset into share
 };
 
@@ -600,6 +601,7 @@ __global__ __launch_bounds__(512) void k_em_step(const WinDesc* __restrict__ win
     __syncthreads();
     double s = s_part[0];                                                    // csrSum, cpopulation.pyx:849
     for (int v = 1; v < n_wav; ++v) s += s_part[v];
+    if (tid == 0) S.csr[W.ind_base + i] = s;
     double* sh = S.share + S.share_base[w] + (int64_t)i * n;
     for (int k = tid; k < n; k += n_thr) {
         const double t = 2.0 * f[k] * y0[k];
@@ -854,6 +856,7 @@ __device__ __forceinline__ void sym_share(const WinDesc& W, int i, const double*
     __syncthreads();
     double s = s_part[0];                                                    // csrSum, cpopulation.pyx:849
     for (int v = 1; v < n_wav; ++v) s += s_part[v];
+    if (tid == 0) S.csr[W.ind_base + i] = s;
     double* sh = S.share + S.share_base[w] + (int64_t)i * n;
     for (int k = tid; k < n; k += n_thr) {
         const double tt = 2.0 * f[k] * y0[k];
@@ -896,16 +899,16 @@ __global__ __launch_bounds__(1024) void k_em_step_sym(const WinDesc* __restrict_
     em_update_window<true>(W, io, S, w, max_iters, tid, blockDim.x, reinterpret_cast<unsigned char*>(em_lds), s_part, s_count);
 }
 
-// Genotype calls (cpopulation.pyx:773-797) from the last iteration's old frequencies, in the shape of
-// k_em_step: one workgroup per (window, individual), matrix rows split between its wavefronts, for the
-// product that gives csrSum and again for the scan of the upper triangle; the wavefronts' best
-// genotypes are compared in wavefront order, i.e. in genotype order (first maximum wins).
+// Genotype calls (cpopulation.pyx:773-797) from the last iteration's old frequencies: one workgroup per
+// (window, individual) scans the upper triangle of the individual's matrix once, its rows split between the
+// wavefronts in ranges of about equal size; csrSum is the one the individual's last step left in S.csr (the
+// step of the frequencies now in f_prev); the wavefronts' best genotypes are compared in wavefront order, i.e.
+// in genotype order (first maximum wins).
 __global__ __launch_bounds__(512) void k_em_calls(const WinDesc* __restrict__ wins, const int32_t* __restrict__ ioff,
                                                   const double* __restrict__ full, EmState S, int n_max,
                                                   int32_t* __restrict__ best_gen, double* __restrict__ best_val)
 {
     extern __shared__ double em_lds[];
-    __shared__ double s_part[8];
     __shared__ double s_bv[8];
     __shared__ int s_bj[8];
     const int w = blockIdx.x;
@@ -925,33 +928,24 @@ __global__ __launch_bounds__(512) void k_em_calls(const WinDesc* __restrict__ wi
     }
     const int n = W.n_hap;
     double* f = em_lds;
-    double* yv = em_lds + n_max + (size_t)wave * n_max;
     const double* f_glob = S.f_prev + W.hap_base;
     for (int k = tid; k < n; k += n_thr) f[k] = f_glob[k];
     __syncthreads();
     const double* P = full + W.full_base + (int64_t)i * n * W.ld;
-    const int rows = (n + n_wav - 1) / n_wav;
-    const int r0 = wave * rows < n ? wave * rows : n, r1 = r0 + rows < n ? r0 + rows : n;
-    for (int k0 = 0; k0 < n; k0 += 256) {
-        const int nc = (n - k0 + 63) >> 6;
-        if (nc >= 4)      matvec_pass<4>(P, f, yv, n, W.ld, k0, lane, r0, r1);
-        else if (nc == 3) matvec_pass<3>(P, f, yv, n, W.ld, k0, lane, r0, r1);
-        else if (nc == 2) matvec_pass<2>(P, f, yv, n, W.ld, k0, lane, r0, r1);
-        else              matvec_pass<1>(P, f, yv, n, W.ld, k0, lane, r0, r1);
+    // rows of the upper triangle dealt to the wavefronts as contiguous ranges of about equal element counts
+    // (ascending: a later wavefront holds later genotypes, which the tie rule below relies on)
+    const int64_t total = (int64_t)n * (n + 1) / 2, per = (total + n_wav - 1) / n_wav;
+    int r0 = n, r1 = n;
+    int64_t before = 0;                                                      // elements of the rows above a
+    for (int a = 0; a < n; ++a) {                                            // a few hundred rows: every thread walks them
+        if ((int)(before / per) == wave) {
+            if (r0 == n) r0 = a;
+            r1 = a + 1;
+        }
+        before += n - a;
     }
-    __syncthreads();
-    double part = 0.0;
-    double* y0 = em_lds + n_max;
-    for (int k = tid; k < n; k += n_thr) {
-        double y = y0[k];
-        for (int v = 1; v < n_wav; ++v) y += y0[(size_t)v * n_max + k];      // wavefront order, as in k_em_step
-        part += f[k] * y;
-    }
-    part = wave_sum(part);
-    if (lane == 0) s_part[wave] = part;
-    __syncthreads();
-    double s = s_part[0];                                                    // csrSum of the last iteration
-    for (int v = 1; v < n_wav; ++v) s += s_part[v];
+    // csrSum of the individual's last step, i.e. of the frequencies in f_prev: the step kernel left it here
+    const double s = S.csr[W.ind_base + i];
     double bv = 0.0;
     int bj = 0x7fffffff;
     for (int a = r0; a < r1; ++a) {

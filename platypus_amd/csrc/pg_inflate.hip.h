@@ -7,7 +7,8 @@
 // stays in its own bank.  A table is canonical: per code length the left-aligned upper end of the codes of up to
 // that length (thr) and the offset of the length's first symbol in the list of symbols sorted by code (base).
 // A symbol is decoded from 15 peeked bits, reversed: its length is the number of thresholds the value has
-// reached -- sixteen independent compares on eight LDS words instead of a bit-by-bit walk.
+// reached -- sixteen independent compares on eight LDS words instead of a bit-by-bit walk.  Literal/length codes of
+// up to ten bits (nearly all) skip even that: a direct table indexed by the next ten bits holds symbol and length.
 //
 // The decoder is one function for device and host (LANES = 64 / 1); the host instantiation exists for the
 // tests, which run it against zlib on the CPU.
@@ -35,7 +36,9 @@ constexpr int IT_DST_SYM = 320, IT_DST_THR = 352, IT_DST_BASE = 368;
 constexpr int IT_CLC_SYM = 384, IT_CLC_THR = 404, IT_CLC_BASE = 420;
 constexpr int IT_POS = 436;
 constexpr int IT_LENS = 452;                   // 320 bytes of code lengths
-constexpr int IT_U16 = 452 + 160;              // 612 16-bit units = 306 words per lane
+constexpr int IT_FAST = 452 + 160;             // direct table of the literal/length codes of up to IT_FAST_BITS bits
+constexpr int IT_FAST_BITS = 10;               // entry = symbol | length << 9, 0 = longer code (thresholds decide)
+constexpr int IT_U16 = IT_FAST + (1 << IT_FAST_BITS);   // 1636 16-bit units = 818 words per lane
 
 template <int LANES>
 struct InflTab {
@@ -86,6 +89,16 @@ struct InflBits {
     __host__ __device__ bool overrun() const { return wi > stop; }
 };
 
+__host__ __device__ inline uint32_t rev_bits(uint32_t x, int n) {   // the low n bits of x, reversed (n >= 1)
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __brev(x) >> (32 - n);
+#else
+    uint32_t r = 0;
+    for (int i = 0; i < n; ++i) r |= ((x >> i) & 1u) << (n - 1 - i);
+    return r;
+#endif
+}
+
 __host__ __device__ inline uint32_t rev15(uint32_t x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __brev(x) >> 17;
@@ -99,7 +112,8 @@ __host__ __device__ inline uint32_t rev15(uint32_t x) {
 // Canonical table of n symbols whose code lengths (0 = unused, at most 15) are u8(lens_region, lens_at + s).
 // Returns false for an over-subscribed set of lengths.
 template <int LANES>
-__host__ __device__ inline bool infl_build(const InflTab<LANES>& T, int lens_region, int lens_at, int n, int sym, int thr, int base) {
+__host__ __device__ inline bool infl_build(const InflTab<LANES>& T, int lens_region, int lens_at, int n, int sym, int thr, int base,
+                                           bool fast = false) {
     for (int l = 0; l < 16; ++l) T.u16(thr, l) = 0;
     for (int s = 0; s < n; ++s) T.u16(thr, T.u8(lens_region, lens_at + s)) += 1;      // counts, for now
     uint32_t code = 0, off = 0;
@@ -115,15 +129,26 @@ __host__ __device__ inline bool infl_build(const InflTab<LANES>& T, int lens_reg
         code = (code + c) << 1;
         off += c;
     }
+    if (!ok) return false;
+    if (fast) {
+        uint32_t* words = reinterpret_cast<uint32_t*>(T.t);
+        for (int w = 0; w < (1 << IT_FAST_BITS) / 2; ++w) words[((IT_FAST >> 1) + w) * LANES] = 0;
+    }
     for (int s = 0; s < n; ++s) {
         const int l = T.u8(lens_region, lens_at + s);
         if (l) {
             const int p = T.u16(IT_POS, l);
             T.u16(sym, p) = (unsigned short)s;
             T.u16(IT_POS, l) = (unsigned short)(p + 1);
+            if (fast && l <= IT_FAST_BITS) {
+                // the symbol's code, as the stream presents it (first bit lowest), and every table index that ends in it
+                const uint32_t code = (uint32_t)(p - T.u16(base, l)) & 0xffffu;
+                const unsigned short entry = (unsigned short)(s | (l << 9));
+                for (uint32_t e = rev_bits(code, l); e < (1u << IT_FAST_BITS); e += 1u << l) T.u16(IT_FAST, (int)e) = entry;
+            }
         }
     }
-    return ok;
+    return true;
 }
 
 // One symbol: returns it, or -1 for a code no symbol has.  The caller has refilled (bc >= 15 is not needed:
@@ -233,13 +258,21 @@ __host__ __device__ inline int infl_block(const InflTab<LANES>& T, const unsigne
                 if (T.u8(IT_LENS, 256) == 0) return INF_BAD_LENGTHS;               // no end-of-block code
                 dst_at = n_lit;
             }
-            if (!infl_build(T, IT_LENS, 0, n_lit, IT_LIT_SYM, IT_LIT_THR, IT_LIT_BASE)) return INF_BAD_LENGTHS;
+            if (!infl_build(T, IT_LENS, 0, n_lit, IT_LIT_SYM, IT_LIT_THR, IT_LIT_BASE, true)) return INF_BAD_LENGTHS;
             if (!infl_build(T, IT_LENS, dst_at, n_dst, IT_DST_SYM, IT_DST_THR, IT_DST_BASE)) return INF_BAD_LENGTHS;
             for (;;) {                                       // symbols of the block: every pass consumes at least one bit
                 B.refill();
                 if (B.overrun()) return INF_INPUT_OVERRUN;
-                int s = infl_decode(T, B, IT_LIT_SYM, IT_LIT_THR, IT_LIT_BASE, n_lit);
-                if (s < 0) return INF_BAD_CODE;
+                int s;
+                const uint32_t quick = T.u16(IT_FAST, (int)((uint32_t)B.bb & ((1u << IT_FAST_BITS) - 1)));
+                if (quick) {                                 // a code of up to ten bits: one look-up
+                    s = (int)(quick & 511u);
+                    B.bb >>= quick >> 9;
+                    B.bc -= (int)(quick >> 9);
+                } else {
+                    s = infl_decode(T, B, IT_LIT_SYM, IT_LIT_THR, IT_LIT_BASE, n_lit);
+                    if (s < 0) return INF_BAD_CODE;
+                }
                 if (s < 256) {
                     if (op >= oend) return INF_OUTPUT_OVERRUN;
                     *op++ = (unsigned char)s;

@@ -1049,6 +1049,7 @@ int pg_caller_launch(pg_ctx* c, int max_iters) {
         S.f = c->d_freq.p; S.f_prev = c->d_fprev.p; S.share = c->d_share.p; S.iters = c->d_em_iters.p;
         S.change = c->d_em_change.p; S.done = c->d_em_done.p; S.active = c->d_em_done.p + c->n_windows; S.arrived = S.active + 1;
         S.share_base = c->d_share_base.p;
+        S.csr = c->d_best_val.p;                            // k_em_calls replaces the sums by the calls' values
         hipLaunchKernelGGL(pg::k_em_init, dim3(c->n_windows), dim3(256), 0, c->stream, c->d_wins.p, c->n_windows, S);
         int32_t active = c->n_windows;
         // wavefronts per individual (the rows of its matrix are split between them): enough to keep loads in
@@ -1227,7 +1228,7 @@ struct pg_inflater {
     std::vector<pg::InflBlock> blocks;
     int32_t* h_status = nullptr;                  // page-locked as well: a copy into pageable memory would make the call spin
     size_t h_status_cap = 0;
-    int lanes = 16;                               // BGZF blocks per wavefront (16, 32 or 64)
+    int lanes = 8;                                // BGZF blocks per wavefront (8, 16 or 32; 3272 bytes of LDS each)
     float last_ms = 0;
     hipEvent_t t0 = nullptr, t1 = nullptr;
     std::string err;
@@ -1363,7 +1364,7 @@ int pg_inflater_input(pg_inflater* h, size_t bytes, void** buf) {
 }
 
 int pg_inflater_set_lanes(pg_inflater* h, int lanes) {
-    if (!h || (lanes != 16 && lanes != 32 && lanes != 64)) return PG_ERR_INVALID;
+    if (!h || (lanes != 8 && lanes != 16 && lanes != 32)) return PG_ERR_INVALID;
     h->lanes = lanes;
     return PG_OK;
 }
@@ -1427,9 +1428,9 @@ int pg_bgzf_inflate(pg_inflater* h, const void* raw_, size_t n_raw, const void* 
     PG_IHIP(h, hipMemcpyAsync(h->d_raw.p, raw, eaten, hipMemcpyHostToDevice, h->stream));
     PG_IHIP(h, hipMemcpyAsync(h->d_blocks.p, h->blocks.data(), (size_t)nb * sizeof(pg::InflBlock), hipMemcpyHostToDevice, h->stream));
     PG_IHIP(h, hipEventRecord(h->t0, h->stream));
-    if (h->lanes == 16) PG_IHIP(h, launch_inflate<16>(h, nb));
-    else if (h->lanes == 32) PG_IHIP(h, launch_inflate<32>(h, nb));
-    else PG_IHIP(h, launch_inflate<64>(h, nb));
+    if (h->lanes == 8) PG_IHIP(h, launch_inflate<8>(h, nb));
+    else if (h->lanes == 16) PG_IHIP(h, launch_inflate<16>(h, nb));
+    else PG_IHIP(h, launch_inflate<32>(h, nb));
     PG_IHIP(h, hipEventRecord(h->t1, h->stream));
     PG_IHIP(h, hipEventRecord(h->done, h->stream));
     // The kernel runs for tens of milliseconds whatever the number of blocks.  The calling thread sleeps in short

@@ -315,7 +315,7 @@ class Inflater(object):
 
     def set_lanes(self, lanes):
         if LIB.pg_inflater_set_lanes(self._h, lanes) != PG_OK:
-            raise ValueError("lanes must be 16, 32 or 64")
+            raise ValueError("lanes must be 8, 16 or 32")
 
     def last_ms(self):
         ms = C.c_float(0)

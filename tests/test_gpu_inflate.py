@@ -42,7 +42,7 @@ def _payloads(rng, n):
     return out
 
 
-@pytest.mark.parametrize("lanes", [16, 32, 64])
+@pytest.mark.parametrize("lanes", [8, 16, 32])
 def test_inflate_equals_zlib(lanes):
     from platypus_amd import native
     rng = np.random.default_rng(100 + lanes)
