@@ -10,4 +10,7 @@ cp $src/kernel_stats_joint.csv $dst/${tag}_kernel_stats_joint.csv
 cp $src/pmc_summary.csv $dst/${tag}_pmc_summary.csv
 cp $src/vote/pmc.csv $dst/${tag}_pmc_vote_panel.csv
 { echo "read_len,kernel,counter,mean_per_dispatch,dispatches"; for L in 100 150 250; do grep "k_align2," $src/valu_L$L.csv | sed "s/^/$L,/"; done; } > $dst/${tag}_valu_insts.csv
+cp $src/inflate_time.txt $dst/${tag}_inflate_time.txt
+cp $src/kernel_stats_inflate.csv $dst/${tag}_kernel_stats_inflate.csv
+cp $src/pmc_inflate.csv $dst/${tag}_pmc_inflate.csv
 ls -la $dst | grep ${tag}_
