@@ -15,7 +15,7 @@ cdef class Variant:
     cdef public double nRevReadsWeighted
     cdef public double freqPrior
     cdef public double rmsReadPos
-    cdef public double sumSqReadPos
+    cdef public long long sumSqReadPos
     cdef long hashValue
     cpdef double calculatePrior(self) except? -1.0
     cpdef addVariant(self, Variant other)

@@ -3,7 +3,7 @@
 sequence, support counters, prior.  Candidate generation from CIGAR strings
 (variant.pyx:253-615) is upstream of the alignment path and not part of this package."""
 from libc.math cimport exp, sqrt
-from libc.stdint cimport int32_t
+from libc.stdint cimport int32_t, int64_t
 from libc.stdlib cimport calloc, malloc, realloc, free
 
 cdef double mLTOT = -0.23025850929940459    # minus log ten over ten
@@ -31,10 +31,12 @@ cdef class Variant:
         self.nFwdReads = nFwdReads
         self.nRevReads = nSupportingReads - nFwdReads
         self.hashValue = -1
-        self.sumSqReadPos = <double>readPos * readPos
+        # the sum of squares is an integer and so is its quotient by the number of reads: variant.pxd declares both
+        # `int`, and variant.pyx:69,119 divides them as integers before the square root
+        self.sumSqReadPos = <long long>readPos * readPos
         self.rmsReadPos = 0.0
         if nSupportingReads > 0:
-            self.rmsReadPos = sqrt(self.sumSqReadPos / nSupportingReads)
+            self.rmsReadPos = sqrt(<double>(self.sumSqReadPos // nSupportingReads))
         if nFwdReads == 1:                                     # variant.pyx:71-76
             self.nFwdReadsWeighted = 1.0 - exp(mLTOT * baseQ)
             self.nRevReadsWeighted = 0.0
@@ -65,7 +67,7 @@ cdef class Variant:
         self.nRevReadsWeighted += other.nRevReadsWeighted
         self.sumSqReadPos += other.sumSqReadPos
         if self.nSupportingReads > 0:
-            self.rmsReadPos = sqrt(self.sumSqReadPos / self.nSupportingReads)
+            self.rmsReadPos = sqrt(<double>(self.sumSqReadPos // self.nSupportingReads))
 
     def __hash__(self):
         if self.hashValue == -1:
@@ -112,7 +114,8 @@ from platypus_amd.cwindow cimport bamReadBuffer
 
 cdef struct SnpSums:
     int32_t slot, n, fwd
-    double sumSq, fwdW, revW
+    int64_t sumSq
+    double fwdW, revW
 
 
 cdef class VariantCandidateGenerator:
@@ -210,10 +213,10 @@ cdef class VariantCandidateGenerator:
                     self.nSnpSums += 1
                     self.snpIndex[slot] = k + 1
                     acc = &self.snpSums[k]
-                    acc.slot = <int32_t>slot; acc.n = 0; acc.fwd = 0; acc.sumSq = 0.0; acc.fwdW = 0.0; acc.revW = 0.0
+                    acc.slot = <int32_t>slot; acc.n = 0; acc.fwd = 0; acc.sumSq = 0; acc.fwdW = 0.0; acc.revW = 0.0
                 acc = &self.snpSums[k]
                 acc.n += 1
-                acc.sumSq += <double>(readIndex + 1) * (readIndex + 1)
+                acc.sumSq += <int64_t>(readIndex + 1) * (readIndex + 1)
                 if read.isReverse:
                     acc.revW += 1.0 - exp(mLTOT * baseQual)
                 else:
@@ -283,15 +286,17 @@ cdef class VariantCandidateGenerator:
             flanked = ((cigarIndex > 0 and read.cigarOps[cigarIndex - 1] == 0 and read.cigarLens[cigarIndex - 1] >= self.minFlank)
                        or (cigarIndex < cigarLength - 1 and read.cigarOps[cigarIndex + 1] == 0
                            and read.cigarLens[cigarIndex + 1] >= self.minFlank))
+            # An 'N' operation moves the read offset too (as the reference has it), so the offsets of what follows can
+            # lie beyond the read: there the reference reads outside its arrays; no candidate is made from that
             if flag == 1 and self.genIndels:                               # insertion
-                if flanked:
+                if flanked and readOffset + length <= read.rlen:
                     inserted = bytes(read.seq[readOffset:readOffset + length])
                     if inserted.count(b"N") == 0:
                         self.addVariantToList(Variant(self.rname, readStart + refOffset - 1, b"", inserted, 1, nFwd,
                                                       mapQ, read.qual[readOffset], readOffset + 1))
                 readOffset += length
             elif flag == 2:                                                # deletion
-                if flanked:
+                if flanked and readOffset < read.rlen:
                     deleted = self.refFile.getSequence(self.rname, readStart + refOffset, readStart + refOffset + length)
                     if deleted.count(b"N") == 0 and self.genIndels:
                         self.addVariantToList(Variant(self.rname, readStart + refOffset - 1, deleted, b"", 1, nFwd,
@@ -353,7 +358,7 @@ cdef class VariantCandidateGenerator:
             v = Variant(self.rname, <int>(slot >> 2) + self.refSeqStart, bytes([self.refSeq[slot >> 2]]),
                         b"ACGT"[slot & 3:(slot & 3) + 1], acc.n, acc.fwd, 0, 0, 0)
             v.sumSqReadPos = acc.sumSq
-            v.rmsReadPos = sqrt(v.sumSqReadPos / acc.n)
+            v.rmsReadPos = sqrt(<double>(v.sumSqReadPos // acc.n))
             v.nFwdReadsWeighted = acc.fwdW
             v.nRevReadsWeighted = acc.revW
             self.addVariantToList(v)

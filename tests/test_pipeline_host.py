@@ -95,7 +95,8 @@ def test_candidates_from_cigars():
     # the sums of variant.pyx:57-76,107-119 over the two reads: weights from the base quality (30), read positions 11 and 10
     w = 1.0 - math.exp(-0.23025850929940459 * 30)
     assert snp.nFwdReadsWeighted == w and snp.nRevReadsWeighted == w
-    assert snp.rmsReadPos == math.sqrt((11.0 * 11.0 + 10.0 * 10.0) / 2) and (snp.minPos, snp.maxPos) == (210, 210)
+    # the mean of the squared read positions is an integer quotient (variant.pxd: int sumSqReadPos, int nSupportingReads)
+    assert snp.rmsReadPos == math.sqrt((11 * 11 + 10 * 10) // 2) and (snp.minPos, snp.maxPos) == (210, 210)
     assert gen.getCandidates() == cands and gen.getCandidates()[1].nSupportingReads == cands[1].nSupportingReads   # no double counting
     ins_seq = b"TTT" if ref[235:236] != b"T" else b"GGG"
     ins = by[(234, b"", ins_seq)]

@@ -38,7 +38,7 @@ def test_variant_identity_order_and_merge():
     assert a == b and hash(a) == hash(b) and a != c and len({a, b, c}) == 2
     a.addVariant(b)
     assert (a.nSupportingReads, a.nFwdReads, a.nRevReads) == (2, 1, 1)
-    assert abs(a.rmsReadPos - np.sqrt((9 + 16) / 2.0)) < 1e-15
+    assert a.rmsReadPos == np.sqrt((9 + 16) // 2)          # integer quotient, as variant.pyx:119 computes it
     # order: name, position, |length change| -- SNPs before indels at one position (variant.pyx:133-141)
     ins = Variant(b"20", 100, b"", b"GG")
     dele = Variant(b"20", 100, b"T", b"")
