@@ -37,7 +37,7 @@ def link_rate():
     return max(rates[1:])
 
 
-def measure(W=32768, N=12, pinned=True, device=0, batch=None):
+def measure(W=32768, N=12, pinned=True, device=0, batch=None, threads=2):
     b = batch if batch is not None else synth.make_batch(n_windows=W, haps_per_window=H, reads_per_window=R, read_len=L)
     n_pairs = W * H * R
 
@@ -52,7 +52,8 @@ def measure(W=32768, N=12, pinned=True, device=0, batch=None):
                                    "read_pos", "read_mapq")}
     blk = dict(hap_lo=np.arange(W, dtype=np.int32) * H, n_haps=np.full(W, H, np.int32),
                read_lo=np.arange(W, dtype=np.int32) * R, n_reads=np.full(W, R, np.int32))
-    ctxs = [native.AlignContext(device), native.AlignContext(device)]
+    n_ctx = max(2, int(threads))
+    ctxs = [native.AlignContext(device) for _ in range(n_ctx)]
     outs = [(host(np.empty(n_pairs, np.int32)), host(np.empty(n_pairs, np.int32)), host(np.empty(n_pairs, np.float64)))
             for _ in ctxs]
 
@@ -76,13 +77,31 @@ def measure(W=32768, N=12, pinned=True, device=0, batch=None):
             for x in o:
                 x[...] = 0
         t0 = time.perf_counter()
-        upload_and_launch(ctxs[0])
-        fetch_async(ctxs[0], outs[0])
-        for k in range(1, N):
-            upload_and_launch(ctxs[k & 1])       # batch k goes up while batch k - 1 is computed and comes down
-            fetch_async(ctxs[k & 1], outs[k & 1])
-            ctxs[(k - 1) & 1].sync()             # batch k - 1 is on the host now
-        ctxs[(N - 1) & 1].sync()
+        if threads:
+            # one host thread per context: an upload call returns when its copies and packing kernels have ended, so a
+            # single thread that feeds both contexts leaves the link idle while it waits (the library calls run
+            # without the interpreter lock)
+            import threading
+
+            def feed(k0):
+                for k in range(k0, N, n_ctx):
+                    upload_and_launch(ctxs[k0])
+                    fetch_async(ctxs[k0], outs[k0])
+                    ctxs[k0].sync()
+
+            workers = [threading.Thread(target=feed, args=(k0,)) for k0 in range(n_ctx)]
+            for w in workers:
+                w.start()
+            for w in workers:
+                w.join()
+        else:
+            upload_and_launch(ctxs[0])
+            fetch_async(ctxs[0], outs[0])
+            for k in range(1, N):
+                upload_and_launch(ctxs[k & 1])       # batch k goes up while batch k - 1 is computed and comes down
+                fetch_async(ctxs[k & 1], outs[k & 1])
+                ctxs[(k - 1) & 1].sync()             # batch k - 1 is on the host now
+            ctxs[(N - 1) & 1].sync()
         dt = (time.perf_counter() - t0) / N
         same = all(np.array_equal(x, y) for o in outs for x, y in zip(o, ref))
     finally:
@@ -91,7 +110,8 @@ def measure(W=32768, N=12, pinned=True, device=0, batch=None):
     up = sum(src[k].nbytes for k in src) + sum(v.nbytes for v in blk.values())
     return dict(ms_per_batch=dt * 1e3, gcups=n_pairs * 16 * (L + 8) / dt / 1e9, pairs_per_s=n_pairs / dt, batches=N,
                 pairs_per_batch=n_pairs, bytes_up=up, bytes_down=n_pairs * 16, upload_gbps=up / dt / 1e9,
-                host_memory="page-locked (pg_host_alloc)" if pinned else "pageable", results_equal_across_batches=same)
+                host_memory="page-locked (pg_host_alloc)" if pinned else "pageable", results_equal_across_batches=same,
+                host_threads=n_ctx if threads else 1)
 
 
 if __name__ == "__main__":
@@ -99,9 +119,11 @@ if __name__ == "__main__":
     N = int(sys.argv[2]) if len(sys.argv) > 2 else 12
     pinned = (int(sys.argv[3]) if len(sys.argv) > 3 else 1) != 0
     print("host-to-device copy of 256 MiB from page-locked memory: %.1f GB/s" % link_rate())
-    m = measure(W, N, pinned)
-    assert m["results_equal_across_batches"]
-    print("%s host memory, %d batches of %d pairs: %.2f ms per batch = %.0f GCUPS (%.1f M pairs/s); up %.0f MB (%.1f GB/s if "
-          "transfers alone filled the time), down %.0f MB" % (m["host_memory"], m["batches"], m["pairs_per_batch"],
-                                                              m["ms_per_batch"], m["gcups"], m["pairs_per_s"] / 1e6,
-                                                              m["bytes_up"] / 1e6, m["upload_gbps"], m["bytes_down"] / 1e6))
+    for threads in (0, 2, 3, 4):
+      m = measure(W, N, pinned, threads=threads)
+      assert m["results_equal_across_batches"]
+      print("host threads: %d" % m["host_threads"])
+      print("%s host memory, %d batches of %d pairs: %.2f ms per batch = %.0f GCUPS (%.1f M pairs/s); up %.0f MB (%.1f GB/s if "
+            "transfers alone filled the time), down %.0f MB" % (m["host_memory"], m["batches"], m["pairs_per_batch"],
+                                                                m["ms_per_batch"], m["gcups"], m["pairs_per_s"] / 1e6,
+                                                                m["bytes_up"] / 1e6, m["upload_gbps"], m["bytes_down"] / 1e6))
