@@ -1227,6 +1227,180 @@ __global__ __launch_bounds__(256) void k_em_small(const WinDesc* __restrict__ wi
 }
 
 // ---------------------------------------------------------------------------
+// k_em_exact: windows of at most 8 haplotypes with every sum of platypus/cpopulation.pyx:807-890 in the
+// REFERENCE'S OWN ORDER, so that the frequencies are the doubles a sequential run of that text gives for the same
+// genotype posteriors (the kernels above regroup the sums into matrix-vector products and agree to 1e-9; a
+// frequency that a sequential run makes exactly 0.5 came out one bit off there, and a p-value printed from it
+// could turn on that bit).  One wavefront per window.  Per iteration: every (individual, genotype) value
+// P f_a f_b (1 + (a != b)) by the lanes side by side (:847); every individual's csrSum by one lane, genotypes in
+// order (:849); the divisions side by side (:852-854); then lane k adds up haplotype k's total over individuals
+// and genotypes in order (:858-880: each total receives the same terms in the same order as the reference's loop
+// nest, which is all its value depends on).  The values live in LDS: n_ind * (n_gen + 1) + 40 doubles per
+// wavefront (`slice` doubles apart).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// A window with ONE individual (the usual case of single-sample calling) needs no LDS: lane j holds genotype j's
+// value, csrSum is added up through lane reads in genotype order, and lane k collects haplotype k's n terms, again
+// in genotype order, through lane permutes (every lane runs the same n steps: a permute reads live lanes only).
+__device__ __forceinline__ void em_exact_one(const WinDesc& W, int w, int lane, const int32_t* __restrict__ io,
+                                             const double* __restrict__ Pw, int max_iters,
+                                             double* __restrict__ freq_out, int32_t* __restrict__ iters_out,
+                                             double* __restrict__ change_out, int32_t* __restrict__ best_gen,
+                                             double* __restrict__ best_val)
+{
+    const int n = W.n_hap, n_gen = W.n_gen;
+    const bool has = io[1] != io[0];
+    const bool gen = lane < n_gen;
+    const int a = gen ? tri_row_of(lane, n) : 0;
+    const int b = gen ? a + (lane - (int)tri_row_start(a, n)) : 0;
+    const double p = gen ? Pw[a * W.ld + b] : 0.0;
+    const double twice = (double)(1 + (a != b));
+    const int k = lane < n ? lane : 0;
+    const int kk = (int)tri_row_start(k, n);
+    double eps = 1.0 / (1 * 2 * 2);                                          // :751
+    eps = eps < 1e-3 ? eps : 1e-3;
+    double max_change = eps + 1;
+    int iters = 0;
+    double fk = 1.0 / n;                                                     // lanes 0..n-1: f_k (every lane starts with the same value)
+    double c = 0.0;
+    while (max_change > eps && iters < max_iters) {                          // :766-768
+        double nf = 0.0;                                                     // no reads: the sums stay empty and 0 / 0 ... see below
+        if (has) {
+            const double fa = __shfl(fk, a), fb = __shfl(fk, b);
+            const double v = gen ? __dmul_rn(__dmul_rn(__dmul_rn(p, fa), fb), twice) : 0.0;      // :847
+            double sum = 0.0;
+            for (int j = 0; j < n_gen; ++j) sum = __dadd_rn(sum, __shfl(v, j));                  // :849
+            c = sum > 0.0 ? __ddiv_rn(v, sum) : v;                                               // :852-854
+            double t = 0.0;
+            for (int m = 0; m < n; ++m) {                                    // :858-880: haplotype k's terms in genotype order
+                const int j = m < k ? (int)tri_row_start(m, n) + k - m : kk + m - k;
+                const double term = __shfl(c, j);
+                t = __dadd_rn(t, m == k ? __dmul_rn(2.0, term) : term);
+            }
+            nf = __ddiv_rn(t, 2.0);                                          // :882-884, one individual with data
+        } else {
+            nf = __ddiv_rn(0.0, 0.0);                                        // tmp / (ploidy * 0): the reference divides by zero here
+        }
+        const double ch = lane < n ? fabs(fk - nf) : 0.0;
+        max_change = wave_max(ch);                                           // :885-888
+        fk = nf;
+        ++iters;
+    }
+    if (lane < n) freq_out[W.hap_base + lane] = fk;
+    if (lane == 0) { iters_out[w] = iters; change_out[w] = max_change; }
+    int best = -1;
+    double mx = 0.0;
+    for (int j = 0; j < n_gen; ++j) {                                        // :773-797
+        const double v = __shfl(c, j);
+        if (best == -1 || v > mx) { mx = v; best = j; }
+    }
+    if (lane == 0) {
+        if (!has) { best_gen[W.ind_base] = -1; best_val[W.ind_base] = 0.0; }
+        else if (iters == 0) { best_gen[W.ind_base] = 0; best_val[W.ind_base] = 0.0; }
+        else { best_gen[W.ind_base] = best; best_val[W.ind_base] = mx; }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_em_exact(const WinDesc* __restrict__ wins, int n_win,
+                                                  const int32_t* __restrict__ ioff,
+                                                  const double* __restrict__ full,
+                                                  int max_iters, int slice,
+                                                  double* __restrict__ freq_out, int32_t* __restrict__ iters_out,
+                                                  double* __restrict__ change_out, int32_t* __restrict__ best_gen,
+                                                  double* __restrict__ best_val)
+{
+    extern __shared__ double em_lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + wave));
+    if (w >= n_win) return;
+    const WinDesc W = wins[w];
+    const int n = W.n_hap, n_gen = W.n_gen, n_ind = W.n_ind, cells = n_ind * n_gen;
+    const int32_t* io = ioff + W.ioff_base;
+    const double* Pw = full + W.full_base;
+    if (n_ind == 1) {
+        em_exact_one(W, w, lane, io, Pw, max_iters, freq_out, iters_out, change_out, best_gen, best_val);
+        return;
+    }
+    double* c = em_lds + (size_t)wave * slice;                                // csr[individual][genotype]
+    double* cs = c + cells;                                                  // csrSum per individual
+    double* f = cs + n_ind;                                                  // frequencies [8]
+    int* gtab = reinterpret_cast<int*>(f + 8);                               // genotype -> a | b << 8   (up to 36)
+    if (lane < n_gen) {
+        const int a = tri_row_of(lane, n);
+        gtab[lane] = a | ((a + (lane - (int)tri_row_start(a, n))) << 8);
+    }
+    if (lane < n) f[lane] = 1.0 / n;                                         // :753,763-764
+    int n_with_data = 0;
+    for (int i = 0; i < n_ind; ++i) n_with_data += io[i + 1] != io[i];
+    double eps = 1.0 / (n_ind * 2 * 2);                                      // :751
+    eps = eps < 1e-3 ? eps : 1e-3;
+    double max_change = eps + 1;
+    int iters = 0;
+    wave_sync();
+    while (max_change > eps && iters < max_iters) {                          // :766-768
+        for (int idx = lane; idx < cells; idx += 64) {
+            const int i = idx / n_gen, j = idx - i * n_gen;
+            if (io[i + 1] == io[i]) continue;                                // :834-835
+            const int g = gtab[j], a = g & 0xff, b = g >> 8;
+            const double p = Pw[(int64_t)i * n * W.ld + a * W.ld + b];
+            c[idx] = __dmul_rn(__dmul_rn(__dmul_rn(p, f[a]), f[b]), (double)(1 + (a != b)));   // :847, left to right
+        }
+        wave_sync();
+        for (int i = lane; i < n_ind; i += 64) {
+            if (io[i + 1] == io[i]) continue;
+            double sum = 0.0;
+            for (int j = 0; j < n_gen; ++j) sum = __dadd_rn(sum, c[i * n_gen + j]);   // :849
+            cs[i] = sum;
+        }
+        wave_sync();
+        for (int idx = lane; idx < cells; idx += 64) {
+            const int i = idx / n_gen;
+            if (io[i + 1] == io[i]) continue;
+            const double sum = cs[i];
+            if (sum > 0.0) c[idx] = __ddiv_rn(c[idx], sum);                  // :852-854
+        }
+        wave_sync();
+        double nf = 0.0, ch = 0.0;
+        if (lane < n) {
+            const int k = lane;
+            const int kk = (int)tri_row_start(k, n);
+            double t = 0.0;
+            for (int i = 0; i < n_ind; ++i) {                                // :858-880, the terms of haplotype k in order
+                if (io[i + 1] == io[i]) continue;
+                const double* ci = c + i * n_gen;
+                for (int a = 0; a < k; ++a) t = __dadd_rn(t, ci[(int)tri_row_start(a, n) + k - a]);
+                t = __dadd_rn(t, __dmul_rn(2.0, ci[kk]));
+                for (int b = k + 1; b < n; ++b) t = __dadd_rn(t, ci[kk + b - k]);
+            }
+            nf = __ddiv_rn(t, (double)(2 * n_with_data));                    // :882-884
+            ch = fabs(f[k] - nf);
+        }
+        max_change = wave_max(ch);                                           // :885-888
+        wave_sync();
+        if (lane < n) f[lane] = nf;
+        wave_sync();
+        ++iters;
+    }
+    if (lane < n) freq_out[W.hap_base + lane] = f[lane];
+    if (lane == 0) { iters_out[w] = iters; change_out[w] = max_change; }
+    for (int i = lane; i < n_ind; i += 64) {                                 // :773-797: the first largest csr of the last iteration
+        if (io[i + 1] == io[i]) { best_gen[W.ind_base + i] = -1; best_val[W.ind_base + i] = 0.0; continue; }
+        if (iters == 0) { best_gen[W.ind_base + i] = 0; best_val[W.ind_base + i] = 0.0; continue; }
+        int best = -1;
+        double mx = 0.0;
+        for (int j = 0; j < n_gen; ++j) {
+            const double v = c[i * n_gen + j];
+            if (best == -1 || v > mx) { mx = v; best = j; }
+        }
+        best_gen[W.ind_base + i] = best; best_val[W.ind_base + i] = mx;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // k_var_post: Population.calculatePosterior, platypus/cpopulation.pyx:515-632.
 // One wavefront per variant.  has_var marks the haplotypes that carry the
 // variant; f' = f restricted to the others and rescaled (:554-580).  Per

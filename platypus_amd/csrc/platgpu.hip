@@ -111,6 +111,7 @@ struct pg_ctx {
     int em_kernel = -1;                  // "em_kernel": 0 small, 1 big, 2 multi
     int64_t em_stage_max = 16384;        // "em_stage_max": doubles of a window the big EM kernel may keep in LDS
     int em_step = -1;                    // "em_step": 0 full matrix, 1 upper triangle (launch-pair EM path)
+    int em_small_exact = -1;             // "em_small": 0 regrouped sums (k_em_small), 1 / default: the reference's order (k_em_exact)
     int em_step_waves = 0;               // "em_step_waves": wavefronts per workgroup of the triangle step (1..8)
     int32_t* h_status = nullptr;         // pinned: status words of the last pair-list preparation
     DevBuf<double> d_exp_score, d_exp_mapq;
@@ -501,6 +502,9 @@ int pg_set_option(pg_ctx* c, const char* name, const char* value) {
     } else if (n == "em_step") {
         if (dflt) c->em_step = -1; else if (v == "full") c->em_step = 0; else if (v == "sym") c->em_step = 1;
         else return fail(c, PG_ERR_INVALID, "em_step: full, sym or default");
+    } else if (n == "em_small") {
+        if (dflt) c->em_small_exact = -1; else if (v == "fast") c->em_small_exact = 0; else if (v == "exact") c->em_small_exact = 1;
+        else return fail(c, PG_ERR_INVALID, "em_small: fast, exact or default");
     } else if (n == "em_step_waves") {
         c->em_step_waves = dflt ? 0 : std::max(1, std::min(16, std::atoi(value)));
     } else if (n == "vote_waves") {
@@ -1034,9 +1038,22 @@ int pg_caller_launch(pg_ctx* c, int max_iters) {
     if (path == 2 && c->max_win_inds > 65535)
         return fail(c, PG_ERR_UNSUPPORTED, "the launch-pair EM path takes at most 65535 individuals per window");
     if (path == 0) {
-        hipLaunchKernelGGL(pg::k_em_small, dim3((c->n_windows + 3) / 4), dim3(256), 0, c->stream,
-                           c->d_wins.p, c->n_windows, c->d_ioff.p, c->d_full.p, max_iters,
-                           c->d_freq.p, c->d_em_iters.p, c->d_em_change.p, c->d_best_gen.p, c->d_best_val.p);
+        // the sums in the reference's own order (k_em_exact) where the window's values fit a wavefront's share of
+        // LDS: four wavefronts per workgroup within 64 KiB, else one within 160 KiB, else the regrouped kernel
+        int64_t slice = 0;
+        for (const pg::WinDesc& W : c->h_wins) slice = std::max<int64_t>(slice, (int64_t)W.n_ind * (W.n_gen + 1) + 40);
+        const int exact_waves = slice * 8 * 4 <= 64 * 1024 ? 4 : (slice * 8 <= 160 * 1024 ? 1 : 0);
+        if (c->em_small_exact != 0 && exact_waves > 0) {
+            const size_t lds_exact = (size_t)slice * 8 * exact_waves;
+            PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_em_exact), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_exact));
+            hipLaunchKernelGGL(pg::k_em_exact, dim3((c->n_windows + exact_waves - 1) / exact_waves), dim3(64 * exact_waves), lds_exact,
+                               c->stream, c->d_wins.p, c->n_windows, c->d_ioff.p, c->d_full.p, max_iters, (int)slice,
+                               c->d_freq.p, c->d_em_iters.p, c->d_em_change.p, c->d_best_gen.p, c->d_best_val.p);
+        } else {
+            hipLaunchKernelGGL(pg::k_em_small, dim3((c->n_windows + 3) / 4), dim3(256), 0, c->stream,
+                               c->d_wins.p, c->n_windows, c->d_ioff.p, c->d_full.p, max_iters,
+                               c->d_freq.p, c->d_em_iters.p, c->d_em_change.p, c->d_best_gen.p, c->d_best_val.p);
+        }
     } else if (path == 1) {
         hipLaunchKernelGGL(pg::k_em, dim3(c->n_windows), dim3(64 * n_wav), lds, c->stream,
                            c->d_wins.p, c->d_ioff.p, c->d_full.p, max_iters, n_max, stage,

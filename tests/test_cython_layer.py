@@ -178,7 +178,12 @@ def test_caller_setup_call_and_variant_posterior():
             if ref["best_gen"][i] < 0:
                 assert pop.genotypeCalls[i] is None and pop.genotypeLikelihoods[i] == 0.0
             else:
-                assert pop.genotypeCalls[i] is gts[ref["best_gen"][i]]
+                if pop.genotypeCalls[i] is not gts[ref["best_gen"][i]]:
+                    # two genotypes whose values agree to the last few bits (the genotype posteriors of device and
+                    # checker differ in theirs): either is the largest, as in tests/test_gpu_caller.py
+                    got = [k for k, g in enumerate(gts) if g is pop.genotypeCalls[i]][0]
+                    c = ref["cisr"][i]
+                    assert abs(c[got] - c[ref["best_gen"][i]]) <= 1e-12 * abs(c[ref["best_gen"][i]])
                 np.testing.assert_allclose(pop.genotypeLikelihoods[i], ref["best_val"][i], rtol=1e-9)
         for k in (1, 2, 4):
             mask = [1 if variants[k] in hp.variantsPy() else 0 for hp in haps]

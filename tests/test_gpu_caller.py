@@ -157,6 +157,7 @@ def test_small_window_kernel_equals_general_kernel(H, n_ind):
         ctx = native.AlignContext(0)
         try:
             ctx.set_option("em_kernel", which)
+            ctx.set_option("em_small", "fast")       # the regrouped small-window kernel (the default adds in the reference's order)
             ctx.upload_batch(b)
             ctx.launch()
             ctx.upload_windows([H] * nw, [n_ind] * nw, np.arange(nw, dtype=np.int64) * H * R, offs)
@@ -236,3 +237,45 @@ def test_genotype_likelihood_kernels(which):
     run_case(n_windows=2, H=257, R=60, n_ind=2, seed=51, indel_frac=0.1, read_len=40, hap_len=200, options=opt)
     run_case(n_windows=9, H=4, R=33, n_ind=3, seed=52, empty=0, options=opt)
     run_case(n_windows=3, H=30, R=90, n_ind=4, seed=53, indel_frac=0.2, options=opt)
+
+
+@pytest.mark.parametrize("H,R,n_ind,W", [(2, 20, 1, 300), (3, 24, 1, 200), (4, 32, 1, 400), (4, 40, 7, 60), (5, 30, 3, 80),
+                                         (8, 40, 1, 50), (8, 60, 12, 30), (2, 100, 50, 20), (8, 200, 50, 6), (6, 36, 9, 40)])
+def test_small_windows_in_the_reference_order_give_its_doubles(H, R, n_ind, W):
+    """k_em_exact adds every sum of EMiteration in the reference's order: run on the genotype posteriors the device
+    itself computed, the CPU restatement of Caller.call returns the SAME doubles -- frequencies, largest change, genotype
+    values -- and the same iteration counts and calls; some individuals have no reads"""
+    from platypus_amd import native
+    from oracle import pyoracle as po
+    rng = np.random.default_rng(H * 1000 + R)
+    b = synth.make_batch(n_windows=W, haps_per_window=H, reads_per_window=R, read_len=60, hap_len=300, indel_hap_frac=0.3,
+                         seed=H * 77 + n_ind)
+    ctx = native.AlignContext(0)
+    try:
+        ctx.upload_batch(b)
+        ctx.launch()
+        offs = [split_reads(rng, R, n_ind, 1 if (w % 4 == 0 and n_ind > 2) else None) for w in range(W)]
+        ctx.upload_windows([H] * W, [n_ind] * W, np.arange(W, dtype=np.int64) * H * R, np.concatenate(offs))
+        ctx.caller_launch(100)
+        res = ctx.caller_fetch()
+        ctx.set_option("em_small", "fast")
+        ctx.caller_launch(100)
+        fast = ctx.caller_fetch()
+    finally:
+        ctx.close()
+    n_gen = H * (H + 1) // 2
+    n_half = 0
+    for w in range(W):
+        post = res["post"][res["cell_off"][w]:res["cell_off"][w + 1]].reshape(n_ind, n_gen)
+        ref = po.caller_call(post, offs[w], H, literal=(w % 2 == 0))
+        assert res["iters"][w] == ref["iters"]
+        f = res["freq"][res["hap_off"][w]:res["hap_off"][w + 1]]
+        assert np.array_equal(f, ref["freq"]), (w, f, ref["freq"])
+        assert res["max_change"][w] == ref["max_change"]
+        assert np.array_equal(res["best_gen"][res["ind_off"][w]:res["ind_off"][w + 1]], ref["best_gen"])
+        assert np.array_equal(res["best_val"][res["ind_off"][w]:res["ind_off"][w + 1]], ref["best_val"])
+        n_half += int(np.sum(f == 0.5))
+        # the regrouped kernel on the same input: same counts, values to 1e-9
+        assert fast["iters"][w] == ref["iters"]
+        np.testing.assert_allclose(fast["freq"][fast["hap_off"][w]:fast["hap_off"][w + 1]], ref["freq"], rtol=RTOL, atol=1e-150)
+    print("frequencies that are exactly 0.5: %d" % n_half)
