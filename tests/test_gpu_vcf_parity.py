@@ -16,6 +16,8 @@ pytestmark = pytest.mark.gpu
     dict(seed=4, spacing=25, n_var=120, indel_frac=0.4),          # crowded: multi-variant windows, multi-allelic sites
     dict(seed=5, coverage=12, error_rate=0.02),
     dict(seed=6, n_samples=2, half_covered=True),                 # an individual without reads: ./.:-1,-1,-1:-1:0
+    dict(seed=11, n_samples=50, coverage=10, G=8000, n_var=30),   # joint calling of 50 samples at 10x
+    dict(seed=12, n_samples=24, coverage=10, G=8000, n_var=60, spacing=40, indel_frac=0.4),     # ... with crowded windows
 ])
 def test_region_vcf_lines_equal_the_restatement(kw):
     from platypus_amd import calign, pipeline
