@@ -72,19 +72,41 @@ def call_chunks(chunks, args, tmpdir):
     if args.inflate == "device":
         inflaters = bamio.InflaterPool.shared(int(os.environ.get("PLATGPU_DEVICE", "0")), args.inflaters)
 
-    def load(unit, split=1):                              # fetch, inflate, decode, filter and trim: all outside the lock
+    def load_piece(unit, k, parts):
+        """records of piece k of the unit's stretch cut into `parts`, one set of arrays per BAM file.  A piece after the
+        first keeps the records that start inside it, so every record of the stretch is in exactly one piece.  Pieces exist
+        at the start of a run only, when nothing can be called before the first stretches are there; they are inflated
+        by the host library whatever --inflate says (a device call takes tens of milliseconds however small)."""
+        (chrom, _, _), s, e = unit
+        if not hasattr(local, "piece_readers"):
+            local.piece_readers = [bamio.BamReader(b) for b in args.bamFiles.split(",")]
+            opened.extend(local.piece_readers)
+        lo, hi = s + (e - s) * k // parts, s + (e - s) * (k + 1) // parts
+        out = []
+        for r in local.piece_readers:
+            try:
+                a = r.fetch(chrom, lo, hi)
+            except KeyError:
+                a = bamio._concat([])
+            out.append(a if k == 0 else bamio.drop_before(a, lo))
+        return out
+
+    def load(unit, pieces=None):                          # fetch, inflate, decode, filter and trim: all outside the lock
         (chrom, _, _), s, e = unit
         if not hasattr(local, "readers"):                 # a file handle per helper thread
             local.readers = [bamio.BamReader(b, inflater=inflaters) for b in args.bamFiles.split(",")]
             opened.extend(local.readers)
         bufs = []
-        for r in local.readers:
+        for bi, r in enumerate(local.readers):
             t0 = time.perf_counter()
-            try:
-                # the run's first stretch is read in pieces side by side: nothing can be called before it is there
-                reads = r.fetch(chrom, s, e) if split <= 1 else bamio.fetch_split(r.fileName, chrom, s, e, split, inflaters)
-            except KeyError:                              # this BAM has no such sequence: no reads from it
-                reads = bamio._concat([])
+            if pieces is not None:                        # the stretch was read in pieces side by side
+                got = [p.result()[bi] for p in pieces]
+                reads = bamio._concat([a for a in got if len(a["pos"])])
+            else:
+                try:
+                    reads = r.fetch(chrom, s, e)
+                except KeyError:                          # this BAM has no such sequence: no reads from it
+                    reads = bamio._concat([])
             reads["chrom"] = chrom.encode()
             t1 = time.perf_counter()
             bufs.append(simulate.buffer_of(reads, s, e, minMapQual=opts.minMapQual, maxReads=int(opts.maxReads),
@@ -109,13 +131,23 @@ def call_chunks(chunks, args, tmpdir):
     n_calls, out, current = 0, None, None
     ahead = max(1, args.readAhead)
     with ThreadPoolExecutor(ahead) as pool:
-        pending = collections.deque(pool.submit(load, u, ahead if k == 0 else 1) for k, u in enumerate(units[:ahead]))
+        # Nothing can be called before the first stretch is there, and the calling thread takes a stretch in a tenth of the
+        # time one helper thread needs to prepare it: the first stretches are read in pieces (12, 6, 4, 3, 2, 2 of them
+        # with twelve helper threads), queued in the order of the stretches, so that the helpers finish stretch 0 together
+        # first, then stretch 1, ... instead of every helper starting a whole stretch of its own.
+        def submit(k, unit):
+            parts = max(1, ahead // (k + 1)) if k < ahead else 1
+            if parts <= 1:
+                return pool.submit(load, unit)
+            return pool.submit(load, unit, [pool.submit(load_piece, unit, j, parts) for j in range(parts)])
+
+        pending = collections.deque(submit(k, u) for k, u in enumerate(units[:ahead]))
         for i, (ch, s, e) in enumerate(units):
             t0 = time.perf_counter()
             bufs, cands = pending.popleft().result()
             spent["wait"] += time.perf_counter() - t0
             if i + ahead < len(units):
-                pending.append(pool.submit(load, units[i + ahead]))
+                pending.append(submit(i + ahead, units[i + ahead]))
             if ch is not current:
                 if out is not None:
                     out.close()
