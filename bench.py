@@ -136,7 +136,7 @@ def end_to_end_leg(kb=2000, coverage=30, copies=32):
                 called.add(int(line.split("\t")[1]) - 1)
         # top level: what the runner does by itself (--inflate auto): one process inflates the BGZF blocks on the GPU,
         # several processes that share a GPU leave it to the host library
-        out_d = {k: by_mode["host" if k.endswith("_host_processes") else "device"][k] for k in by_mode["device"]}
+        out_d = {k: by_mode["host" if k.endswith("8_host_processes") else "device"][k] for k in by_mode["device"]}
         out_d["by_inflate_mode"] = by_mode
         out_d.update({
                 "genome_kb": kb * copies, "simulated_kb": kb, "repeats": copies, "coverage": coverage,
@@ -144,8 +144,8 @@ def end_to_end_leg(kb=2000, coverage=30, copies=32):
                 "reads": int(len(reads["pos"])), "bam_mb": os.path.getsize(bam) / 1e6, "vcf_records": len(called),
                 "planted_variants": len(truth), "planted_found": sum(p in called for p, r, a, g in truth),
                 "processes": 1, "what": "simulated BAM + .bai and FASTA + .fai -> VCF, platypus_amd.runner in a process of its own, "
-                                        "start-up included; BGZF blocks inflated on the GPU by the single process, by the host "
-                                        "library when four or eight processes share the GPU (runner --inflate auto); by_inflate_mode: every combination"})
+                                        "start-up included; BGZF blocks inflated on the GPU with one or four host processes, by the host "
+                                        "library with eight (runner --inflate auto); by_inflate_mode: every combination"})
         return out_d
     finally:
         shutil.rmtree(work, ignore_errors=True)
@@ -333,7 +333,7 @@ def main():
         try:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import time_stream
-            streamed = time_stream.measure(W=n_windows, N=12, pinned=True, device=device, batch=batch, threads=3)
+            streamed = time_stream.measure(W=n_windows, N=16, pinned=True, device=device, batch=batch, threads=4)
             streamed["link_gbps"] = time_stream.link_rate()
             streamed["what"] = ("haplotypes, reads and window blocks uploaded, kernels run, score / anchor / likelihood "
                                 "fetched for every batch; bytes_up / link_gbps is the least a batch can take")

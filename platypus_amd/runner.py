@@ -213,9 +213,9 @@ def main(argv=None):
                          "under a few buffer threads was measured and is slower")
     ap.add_argument("--inflate", choices=["auto", "device", "host"], default="auto",
                     help="where the BGZF blocks of the BAM files are inflated: on the GPU (one lane per block; a third fewer "
-                         "host core-seconds per Mb) or by the host library on the helper threads.  auto: on the GPU when one "
-                         "host process drives a GPU, by the host library when several share one (they are there to use the "
-                         "host's spare cores, and their many inflater streams would take turns on the device)")
+                         "host core-seconds per Mb) or by the host library on the helper threads.  auto: on the GPU while at most "
+                         "four host processes share a GPU, by the host library beyond (measured on 16 cores per GPU: with eight "
+                         "processes their inflater streams take turns on the device and the cores are there to be used)")
     ap.add_argument("--inflaters", type=int, default=None,
                     help="device inflaters of a host process, shared by its helper threads (default: 4 for a single process, "
                          "2 per process otherwise)")
@@ -254,7 +254,7 @@ def main(argv=None):
     if args.inflaters is None:
         args.inflaters = 4 if n_workers == 1 else 2
     if args.inflate == "auto":
-        args.inflate = "device" if max(1, args.workersPerGPU) == 1 else "host"
+        args.inflate = "device" if max(1, args.workersPerGPU) <= 4 else "host"
     weights = None
     if n_workers > 1:                                       # longest first by the reads a chunk holds, as far as the
         from platypus_amd import bamio                      # BAM indexes tell (compressed bytes), else by length
