@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 3
+#define PG_ABI_VERSION 4
 
 enum {
     PG_OK = 0,
