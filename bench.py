@@ -327,7 +327,7 @@ def main():
         caller = {"error": str(e)}
 
     # ---- PCIe-inclusive rate, never `value`: the same batch streamed from page-locked host memory through the
-    # ABI (everything uploaded and fetched per batch, two contexts taking turns), beside the link's own rate ----
+    # ABI (everything uploaded and fetched per batch, four contexts fed by a host thread each), beside the link's own rate ----
     streamed = None
     if world == 1 and not args.no_stream and args.workload == "wgs":
         try:
