@@ -39,6 +39,8 @@ struct WinDesc {
     int64_t ind_base;    // into per-individual outputs
 };
 
+constexpr int kExactMaxHaps = 8;   // windows of up to this many haplotypes can go to k_em_exact (sums in the reference's order)
+
 __device__ __forceinline__ int64_t tri_row_start(int a, int n) { return (int64_t)a * n - (int64_t)a * (a - 1) / 2; }
 
 // row a of packed index g: largest a with tri_row_start(a) <= g
@@ -491,7 +493,7 @@ __device__ __forceinline__ void em_window(double* em_lds, double* s_red, int* s_
 __global__ __launch_bounds__(1024) void k_em(const WinDesc* __restrict__ wins,
                                              const int32_t* __restrict__ ioff,
                                              const double* __restrict__ full,
-                                             int max_iters, int n_max, int staged,
+                                             int max_iters, int n_max, int staged, int skip_small,
                                              double* __restrict__ freq_out, int32_t* __restrict__ iters_out,
                                              double* __restrict__ change_out, int32_t* __restrict__ best_gen,
                                              double* __restrict__ best_val)
@@ -500,6 +502,7 @@ __global__ __launch_bounds__(1024) void k_em(const WinDesc* __restrict__ wins,
     __shared__ double s_red[16];
     __shared__ int s_with_data;
     const WinDesc W0 = wins[blockIdx.x];           // windows whose matrices fit the staging area keep them in LDS
+    if (skip_small && W0.n_hap <= kExactMaxHaps) return;                     // k_em_exact's windows
     if ((int64_t)W0.n_ind * W0.n_hap * W0.n_hap <= (int64_t)staged)
         em_window<true>(em_lds, s_red, &s_with_data, wins, ioff, full, max_iters, n_max,
                         freq_out, iters_out, change_out, best_gen, best_val);
@@ -536,10 +539,20 @@ struct EmState {
     const int64_t* share_base;   // per window: offset into share
 };
 
-__global__ __launch_bounds__(256) void k_em_init(const WinDesc* __restrict__ wins, int n_win, EmState S)
+// skip_small: windows of up to kExactMaxHaps haplotypes belong to k_em_exact; they count as done from the start
+// (n_running = the number of the others)
+__global__ __launch_bounds__(256) void k_em_init(const WinDesc* __restrict__ wins, int n_win, EmState S, int skip_small,
+                                                 int n_running)
 {
     const int w = blockIdx.x;
     const WinDesc W = wins[w];
+    if (skip_small && W.n_hap <= kExactMaxHaps) {
+        if (threadIdx.x == 0) {
+            S.done[w] = 1; S.arrived[w] = 0; S.iters[w] = 0;
+            if (w == 0) *S.active = n_running;
+        }
+        return;
+    }
     for (int k = threadIdx.x; k < W.n_hap; k += 256) {
         S.f[W.hap_base + k] = 1.0 / W.n_hap;                                 // cpopulation.pyx:753,763-764
         S.f_prev[W.hap_base + k] = 1.0 / W.n_hap;
@@ -548,7 +561,7 @@ __global__ __launch_bounds__(256) void k_em_init(const WinDesc* __restrict__ win
         double eps = 1.0 / (W.n_ind * 2 * 2);
         eps = eps < 1e-3 ? eps : 1e-3;
         S.iters[w] = 0; S.change[w] = eps + 1; S.done[w] = 0; S.arrived[w] = 0;   // cpopulation.pyx:751-752
-        if (w == 0) *S.active = n_win;
+        if (w == 0) *S.active = skip_small ? n_running : n_win;
     }
 }
 
@@ -905,7 +918,7 @@ __global__ __launch_bounds__(1024) void k_em_step_sym(const WinDesc* __restrict_
 // step of the frequencies now in f_prev); the wavefronts' best genotypes are compared in wavefront order, i.e.
 // in genotype order (first maximum wins).
 __global__ __launch_bounds__(512) void k_em_calls(const WinDesc* __restrict__ wins, const int32_t* __restrict__ ioff,
-                                                  const double* __restrict__ full, EmState S, int n_max,
+                                                  const double* __restrict__ full, EmState S, int n_max, int skip_small,
                                                   int32_t* __restrict__ best_gen, double* __restrict__ best_val)
 {
     extern __shared__ double em_lds[];
@@ -915,6 +928,7 @@ __global__ __launch_bounds__(512) void k_em_calls(const WinDesc* __restrict__ wi
     const WinDesc W = wins[w];
     const int i = blockIdx.y;
     if (i >= W.n_ind) return;
+    if (skip_small && W.n_hap <= kExactMaxHaps) return;                      // k_em_exact's windows
     const int32_t* io = ioff + W.ioff_base;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_thr = blockDim.x, n_wav = n_thr >> 6;
@@ -1318,6 +1332,7 @@ __global__ __launch_bounds__(256) void k_em_exact(const WinDesc* __restrict__ wi
     const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + wave));
     if (w >= n_win) return;
     const WinDesc W = wins[w];
+    if (W.n_hap > kExactMaxHaps) return;                                     // a wider window of a mixed batch: the other kernels' work
     const int n = W.n_hap, n_gen = W.n_gen, n_ind = W.n_ind, cells = n_ind * n_gen;
     const int32_t* io = ioff + W.ioff_base;
     const double* Pw = full + W.full_base;

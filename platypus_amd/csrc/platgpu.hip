@@ -1031,6 +1031,25 @@ int pg_caller_launch(pg_ctx* c, int max_iters) {
     // the LDS staging area, one workgroup per window iterates on them there; otherwise every iteration is a
     // launch pair over (window, individual) workgroups, so that the whole chip streams the matrices.
     // pg_set_option("em_kernel", small | big | multi) forces one of them (tests, measurements).
+    // Windows of up to eight haplotypes add their EM sums in the reference's own order (k_em_exact) where their values fit
+    // a wavefront's share of LDS: four wavefronts per workgroup within 64 KiB, else one within 160 KiB.  In a batch that
+    // also holds wider windows the two kinds go to their own kernels (split): the wider ones' kernels return at once for
+    // the small ones and the other way round.
+    int64_t slice = 0;
+    int n_small = 0;
+    for (const pg::WinDesc& W : c->h_wins)
+        if (W.n_hap <= pg::kExactMaxHaps) { slice = std::max<int64_t>(slice, (int64_t)W.n_ind * (W.n_gen + 1) + 40); ++n_small; }
+    const int exact_waves = n_small == 0 ? 0 : (slice * 8 * 4 <= 64 * 1024 ? 4 : (slice * 8 <= 160 * 1024 ? 1 : 0));
+    const bool exact = c->em_small_exact != 0 && exact_waves > 0;
+    const int split = exact && n_small < c->n_windows ? 1 : 0;              // both kinds in this batch
+    auto launch_exact = [&]() -> int {
+        const size_t lds_exact = (size_t)slice * 8 * exact_waves;
+        PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_em_exact), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_exact));
+        hipLaunchKernelGGL(pg::k_em_exact, dim3((c->n_windows + exact_waves - 1) / exact_waves), dim3(64 * exact_waves), lds_exact,
+                           c->stream, c->d_wins.p, c->n_windows, c->d_ioff.p, c->d_full.p, max_iters, (int)slice,
+                           c->d_freq.p, c->d_em_iters.p, c->d_em_change.p, c->d_best_gen.p, c->d_best_val.p);
+        return PG_OK;
+    };
     int path = n_max <= 8 ? 0 : (c->max_win_full > (int64_t)stage && c->max_win_inds <= 65535 ? 2 : 1);
     if (c->em_kernel == 1) path = 1;
     if (c->em_kernel == 2) path = 2;
@@ -1038,17 +1057,9 @@ int pg_caller_launch(pg_ctx* c, int max_iters) {
     if (path == 2 && c->max_win_inds > 65535)
         return fail(c, PG_ERR_UNSUPPORTED, "the launch-pair EM path takes at most 65535 individuals per window");
     if (path == 0) {
-        // the sums in the reference's own order (k_em_exact) where the window's values fit a wavefront's share of
-        // LDS: four wavefronts per workgroup within 64 KiB, else one within 160 KiB, else the regrouped kernel
-        int64_t slice = 0;
-        for (const pg::WinDesc& W : c->h_wins) slice = std::max<int64_t>(slice, (int64_t)W.n_ind * (W.n_gen + 1) + 40);
-        const int exact_waves = slice * 8 * 4 <= 64 * 1024 ? 4 : (slice * 8 <= 160 * 1024 ? 1 : 0);
-        if (c->em_small_exact != 0 && exact_waves > 0) {
-            const size_t lds_exact = (size_t)slice * 8 * exact_waves;
-            PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_em_exact), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_exact));
-            hipLaunchKernelGGL(pg::k_em_exact, dim3((c->n_windows + exact_waves - 1) / exact_waves), dim3(64 * exact_waves), lds_exact,
-                               c->stream, c->d_wins.p, c->n_windows, c->d_ioff.p, c->d_full.p, max_iters, (int)slice,
-                               c->d_freq.p, c->d_em_iters.p, c->d_em_change.p, c->d_best_gen.p, c->d_best_val.p);
+        if (exact) {
+            const int rc = launch_exact();
+            if (rc != PG_OK) return rc;
         } else {
             hipLaunchKernelGGL(pg::k_em_small, dim3((c->n_windows + 3) / 4), dim3(256), 0, c->stream,
                                c->d_wins.p, c->n_windows, c->d_ioff.p, c->d_full.p, max_iters,
@@ -1056,8 +1067,12 @@ int pg_caller_launch(pg_ctx* c, int max_iters) {
         }
     } else if (path == 1) {
         hipLaunchKernelGGL(pg::k_em, dim3(c->n_windows), dim3(64 * n_wav), lds, c->stream,
-                           c->d_wins.p, c->d_ioff.p, c->d_full.p, max_iters, n_max, stage,
+                           c->d_wins.p, c->d_ioff.p, c->d_full.p, max_iters, n_max, stage, split,
                            c->d_freq.p, c->d_em_iters.p, c->d_em_change.p, c->d_best_gen.p, c->d_best_val.p);
+        if (split) {
+            const int rc = launch_exact();
+            if (rc != PG_OK) return rc;
+        }
     } else {
         PG_HIP(c, c->d_fprev.reserve((size_t)c->win_haps_total + 1));
         PG_HIP(c, c->d_share.reserve((size_t)c->win_share + 1));
@@ -1067,8 +1082,9 @@ int pg_caller_launch(pg_ctx* c, int max_iters) {
         S.change = c->d_em_change.p; S.done = c->d_em_done.p; S.active = c->d_em_done.p + c->n_windows; S.arrived = S.active + 1;
         S.share_base = c->d_share_base.p;
         S.csr = c->d_best_val.p;                            // k_em_calls replaces the sums by the calls' values
-        hipLaunchKernelGGL(pg::k_em_init, dim3(c->n_windows), dim3(256), 0, c->stream, c->d_wins.p, c->n_windows, S);
-        int32_t active = c->n_windows;
+        hipLaunchKernelGGL(pg::k_em_init, dim3(c->n_windows), dim3(256), 0, c->stream, c->d_wins.p, c->n_windows, S, split,
+                           c->n_windows - n_small);
+        int32_t active = c->n_windows - (split ? n_small : 0);
         // wavefronts per individual (the rows of its matrix are split between them): enough to keep loads in
         // flight for a large matrix, one for a small one
         const int step_threads = n_max <= 64 ? 64 : (n_max <= 128 ? 256 : 512);
@@ -1100,7 +1116,7 @@ int pg_caller_launch(pg_ctx* c, int max_iters) {
         // pinned host memory; the host reads the answer of block b only after it has queued block b + 1, so the
         // device never waits for the host (a converged window's workgroups return at once: the one block that
         // may be queued in vain costs a few empty launches).
-        c->h_active[0] = c->h_active[1] = c->n_windows;
+        c->h_active[0] = c->h_active[1] = active;
         const size_t lds_update = (size_t)((c->max_win_inds + 15) & ~15);
         PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_em_update), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_update));
         const int n_blocks = (max_iters + 7) / 8;
@@ -1120,10 +1136,13 @@ int pg_caller_launch(pg_ctx* c, int max_iters) {
             PG_HIP(c, hipMemcpyAsync(&c->h_active[b & 1], S.active, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
             PG_HIP(c, hipEventRecord(c->ev_block[b & 1], c->stream));
         }
-        (void)active;
         PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_em_calls), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_step));
         hipLaunchKernelGGL(pg::k_em_calls, dim3(c->n_windows, c->max_win_inds), dim3(step_threads), lds_step, c->stream,
-                           c->d_wins.p, c->d_ioff.p, c->d_full.p, S, n_max, c->d_best_gen.p, c->d_best_val.p);
+                           c->d_wins.p, c->d_ioff.p, c->d_full.p, S, n_max, split, c->d_best_gen.p, c->d_best_val.p);
+        if (split) {                                        // after the wider windows' kernels: it writes the small windows' outputs
+            const int rc = launch_exact();
+            if (rc != PG_OK) return rc;
+        }
     }
     PG_HIP(c, hipGetLastError());
     PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_CALLER_EM + 1], c->stream));

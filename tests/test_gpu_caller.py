@@ -279,3 +279,48 @@ def test_small_windows_in_the_reference_order_give_its_doubles(H, R, n_ind, W):
         assert fast["iters"][w] == ref["iters"]
         np.testing.assert_allclose(fast["freq"][fast["hap_off"][w]:fast["hap_off"][w + 1]], ref["freq"], rtol=RTOL, atol=1e-150)
     print("frequencies that are exactly 0.5: %d" % n_half)
+
+
+@pytest.mark.parametrize("options", [(), (("em_kernel", "big"),), (("em_kernel", "multi"),), (("em_kernel", "multi"), ("em_step", "full")),
+                                     (("em_kernel", "multi"), ("em_stage_max", "0"))])
+def test_mixed_batch_small_windows_keep_the_reference_order(options):
+    """a batch with windows of up to eight haplotypes AND wider ones: the small ones still get the reference's order (the
+    CPU restatement returns their doubles from the device's genotype posteriors), the wider ones agree to 1e-9, whichever
+    kernels take the wider ones"""
+    from platypus_amd import native
+    from oracle import pyoracle as po
+    H, R, n_ind, W = 12, 48, 5, 36
+    rng = np.random.default_rng(404)
+    b = synth.make_batch(n_windows=W, haps_per_window=H, reads_per_window=R, read_len=60, hap_len=300, indel_hap_frac=0.3, seed=404)
+    n_haps = [int(x) for x in rng.choice([2, 3, 4, 8, 9, 12], size=W)]
+    n_haps[0], n_haps[1] = 12, 4                                      # both kinds are there
+    ctx = native.AlignContext(0)
+    try:
+        for name, value in options:
+            ctx.set_option(name, value)
+        ctx.upload_batch(b)
+        ctx.launch()
+        offs = [split_reads(rng, R, n_ind, 2 if w % 5 == 0 else None) for w in range(W)]
+        ctx.upload_windows(n_haps, [n_ind] * W, np.arange(W, dtype=np.int64) * H * R, np.concatenate(offs))
+        ctx.caller_launch(100)
+        res = ctx.caller_fetch()
+    finally:
+        ctx.close()
+    n_small = 0
+    for w in range(W):
+        n = n_haps[w]
+        n_gen = n * (n + 1) // 2
+        post = res["post"][res["cell_off"][w]:res["cell_off"][w + 1]].reshape(n_ind, n_gen)
+        ref = po.caller_call(post, offs[w], n)
+        f = res["freq"][res["hap_off"][w]:res["hap_off"][w + 1]]
+        best = res["best_gen"][res["ind_off"][w]:res["ind_off"][w + 1]]
+        val = res["best_val"][res["ind_off"][w]:res["ind_off"][w + 1]]
+        assert res["iters"][w] == ref["iters"], (w, n)
+        if n <= 8:
+            n_small += 1
+            assert np.array_equal(f, ref["freq"]) and res["max_change"][w] == ref["max_change"], (w, n)
+            assert np.array_equal(best, ref["best_gen"]) and np.array_equal(val, ref["best_val"]), (w, n)
+        else:
+            np.testing.assert_allclose(f, ref["freq"], rtol=RTOL, atol=1e-150)
+            np.testing.assert_allclose(val, ref["best_val"], rtol=RTOL, atol=1e-300)
+    assert 0 < n_small < W
