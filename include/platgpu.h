@@ -87,7 +87,7 @@ int pg_set_params(pg_ctx *ctx, int gapextend, int nucprior, const char *table, i
  * No counterpart in the reference.  Options (value "default" or "" restores the
  * library's choice):
  *   "em_kernel"      small | big | multi   EM path of pg_caller_launch
- *   "em_small"       exact | fast          windows of up to 8 haplotypes: EM sums in the reference's own order
+ *   "em_small"       exact | fast          windows of up to 8 haplotypes (16 while light): EM sums in the reference's own order
  *                                          (the default: its doubles) or regrouped (faster, equal to 1e-9)
  *   "gl_kernel"      cell | tile           genotype-likelihood kernel of pg_caller_launch
  *   "em_stage_max"   doubles of one window the "big" EM kernel may keep in LDS

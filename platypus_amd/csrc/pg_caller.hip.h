@@ -39,7 +39,14 @@ struct WinDesc {
     int64_t ind_base;    // into per-individual outputs
 };
 
-constexpr int kExactMaxHaps = 8;   // windows of up to this many haplotypes can go to k_em_exact (sums in the reference's order)
+// Windows that k_em_exact takes (EM sums in the reference's own order): up to 8 haplotypes whatever the number of
+// individuals (the host checks that the largest of them fits the LDS), and up to 16 haplotypes while the window's
+// values fit 16 KiB (a single sample's windows always do).  Host and kernels share this predicate.
+constexpr int kExactMaxHaps = 8, kExactMaxHapsLight = 16, kExactLightCells = 2000;
+__host__ __device__ inline bool em_is_exact(int n_hap, int n_ind, int n_gen) {
+    return n_hap <= kExactMaxHaps || (n_hap <= kExactMaxHapsLight && (long long)n_ind * (n_gen + 1) <= kExactLightCells);
+}
+constexpr int kExactPad = 96;      // doubles of a wavefront's LDS slice beside the values: frequencies [16], genotype table [136 ints]
 
 __device__ __forceinline__ int64_t tri_row_start(int a, int n) { return (int64_t)a * n - (int64_t)a * (a - 1) / 2; }
 
@@ -502,7 +509,7 @@ __global__ __launch_bounds__(1024) void k_em(const WinDesc* __restrict__ wins,
     __shared__ double s_red[16];
     __shared__ int s_with_data;
     const WinDesc W0 = wins[blockIdx.x];           // windows whose matrices fit the staging area keep them in LDS
-    if (skip_small && W0.n_hap <= kExactMaxHaps) return;                     // k_em_exact's windows
+    if (skip_small && em_is_exact(W0.n_hap, W0.n_ind, W0.n_gen)) return;     // k_em_exact's windows
     if ((int64_t)W0.n_ind * W0.n_hap * W0.n_hap <= (int64_t)staged)
         em_window<true>(em_lds, s_red, &s_with_data, wins, ioff, full, max_iters, n_max,
                         freq_out, iters_out, change_out, best_gen, best_val);
@@ -539,14 +546,14 @@ struct EmState {
     const int64_t* share_base;   // per window: offset into share
 };
 
-// skip_small: windows of up to kExactMaxHaps haplotypes belong to k_em_exact; they count as done from the start
+// skip_small: the windows em_is_exact names belong to k_em_exact; they count as done from the start
 // (n_running = the number of the others)
 __global__ __launch_bounds__(256) void k_em_init(const WinDesc* __restrict__ wins, int n_win, EmState S, int skip_small,
                                                  int n_running)
 {
     const int w = blockIdx.x;
     const WinDesc W = wins[w];
-    if (skip_small && W.n_hap <= kExactMaxHaps) {
+    if (skip_small && em_is_exact(W.n_hap, W.n_ind, W.n_gen)) {
         if (threadIdx.x == 0) {
             S.done[w] = 1; S.arrived[w] = 0; S.iters[w] = 0;
             if (w == 0) *S.active = n_running;
@@ -928,7 +935,7 @@ __global__ __launch_bounds__(512) void k_em_calls(const WinDesc* __restrict__ wi
     const WinDesc W = wins[w];
     const int i = blockIdx.y;
     if (i >= W.n_ind) return;
-    if (skip_small && W.n_hap <= kExactMaxHaps) return;                      // k_em_exact's windows
+    if (skip_small && em_is_exact(W.n_hap, W.n_ind, W.n_gen)) return;        // k_em_exact's windows
     const int32_t* io = ioff + W.ioff_base;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_thr = blockDim.x, n_wav = n_thr >> 6;
@@ -1241,7 +1248,7 @@ __global__ __launch_bounds__(256) void k_em_small(const WinDesc* __restrict__ wi
 }
 
 // ---------------------------------------------------------------------------
-// k_em_exact: windows of at most 8 haplotypes with every sum of platypus/cpopulation.pyx:807-890 in the
+// k_em_exact: the windows em_is_exact names (at most 8 haplotypes, or 16 while small) with every sum of platypus/cpopulation.pyx:807-890 in the
 // REFERENCE'S OWN ORDER, so that the frequencies are the doubles a sequential run of that text gives for the same
 // genotype posteriors (the kernels above regroup the sums into matrix-vector products and agree to 1e-9; a
 // frequency that a sequential run makes exactly 0.5 came out one bit off there, and a p-value printed from it
@@ -1249,7 +1256,7 @@ __global__ __launch_bounds__(256) void k_em_small(const WinDesc* __restrict__ wi
 // P f_a f_b (1 + (a != b)) by the lanes side by side (:847); every individual's csrSum by one lane, genotypes in
 // order (:849); the divisions side by side (:852-854); then lane k adds up haplotype k's total over individuals
 // and genotypes in order (:858-880: each total receives the same terms in the same order as the reference's loop
-// nest, which is all its value depends on).  The values live in LDS: n_ind * (n_gen + 1) + 40 doubles per
+// nest, which is all its value depends on).  The values live in LDS: n_ind * (n_gen + 1) + kExactPad doubles per
 // wavefront (`slice` doubles apart).
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void wave_sync() {
@@ -1332,21 +1339,21 @@ __global__ __launch_bounds__(256) void k_em_exact(const WinDesc* __restrict__ wi
     const int w = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + wave));
     if (w >= n_win) return;
     const WinDesc W = wins[w];
-    if (W.n_hap > kExactMaxHaps) return;                                     // a wider window of a mixed batch: the other kernels' work
+    if (!em_is_exact(W.n_hap, W.n_ind, W.n_gen)) return;                     // a wider window of a mixed batch: the other kernels' work
     const int n = W.n_hap, n_gen = W.n_gen, n_ind = W.n_ind, cells = n_ind * n_gen;
     const int32_t* io = ioff + W.ioff_base;
     const double* Pw = full + W.full_base;
-    if (n_ind == 1) {
+    if (n_ind == 1 && n_gen <= 64) {
         em_exact_one(W, w, lane, io, Pw, max_iters, freq_out, iters_out, change_out, best_gen, best_val);
         return;
     }
     double* c = em_lds + (size_t)wave * slice;                                // csr[individual][genotype]
     double* cs = c + cells;                                                  // csrSum per individual
-    double* f = cs + n_ind;                                                  // frequencies [8]
-    int* gtab = reinterpret_cast<int*>(f + 8);                               // genotype -> a | b << 8   (up to 36)
-    if (lane < n_gen) {
-        const int a = tri_row_of(lane, n);
-        gtab[lane] = a | ((a + (lane - (int)tri_row_start(a, n))) << 8);
+    double* f = cs + n_ind;                                                  // frequencies [16]
+    int* gtab = reinterpret_cast<int*>(f + kExactMaxHapsLight);              // genotype -> a | b << 8   (up to 136)
+    for (int j = lane; j < n_gen; j += 64) {
+        const int a = tri_row_of(j, n);
+        gtab[j] = a | ((a + (j - (int)tri_row_start(a, n))) << 8);
     }
     if (lane < n) f[lane] = 1.0 / n;                                         // :753,763-764
     int n_with_data = 0;

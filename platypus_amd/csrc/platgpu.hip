@@ -1038,7 +1038,7 @@ int pg_caller_launch(pg_ctx* c, int max_iters) {
     int64_t slice = 0;
     int n_small = 0;
     for (const pg::WinDesc& W : c->h_wins)
-        if (W.n_hap <= pg::kExactMaxHaps) { slice = std::max<int64_t>(slice, (int64_t)W.n_ind * (W.n_gen + 1) + 40); ++n_small; }
+        if (pg::em_is_exact(W.n_hap, W.n_ind, W.n_gen)) { slice = std::max<int64_t>(slice, (int64_t)W.n_ind * (W.n_gen + 1) + pg::kExactPad); ++n_small; }
     const int exact_waves = n_small == 0 ? 0 : (slice * 8 * 4 <= 64 * 1024 ? 4 : (slice * 8 <= 160 * 1024 ? 1 : 0));
     const bool exact = c->em_small_exact != 0 && exact_waves > 0;
     const int split = exact && n_small < c->n_windows ? 1 : 0;              // both kinds in this batch
@@ -1050,10 +1050,11 @@ int pg_caller_launch(pg_ctx* c, int max_iters) {
                            c->d_freq.p, c->d_em_iters.p, c->d_em_change.p, c->d_best_gen.p, c->d_best_val.p);
         return PG_OK;
     };
-    int path = n_max <= 8 ? 0 : (c->max_win_full > (int64_t)stage && c->max_win_inds <= 65535 ? 2 : 1);
+    const bool small_only = n_max <= 8 || (exact && n_small == c->n_windows);   // nothing for the wider windows' kernels
+    int path = small_only ? 0 : (c->max_win_full > (int64_t)stage && c->max_win_inds <= 65535 ? 2 : 1);
     if (c->em_kernel == 1) path = 1;
     if (c->em_kernel == 2) path = 2;
-    if (c->em_kernel == 0 && n_max <= 8) path = 0;
+    if (c->em_kernel == 0 && small_only) path = 0;
     if (path == 2 && c->max_win_inds > 65535)
         return fail(c, PG_ERR_UNSUPPORTED, "the launch-pair EM path takes at most 65535 individuals per window");
     if (path == 0) {
