@@ -1474,12 +1474,17 @@ int pg_bgzf_inflate(pg_inflater* h, const void* raw_, size_t n_raw, const void* 
     // steps instead of spinning on the event (helper threads share the host's cores with the thread that calls
     // variants), and the copies back are queued only once the kernel has ended: a copy that waits for a kernel
     // inside a copy engine's queue holds up the copies of every other stream behind it.
-    usleep(15000);
+    {   // a lane needs about 0.4 us per byte of its block: sleep through most of the largest block's time, then poll
+        uint32_t longest = 0;
+        for (const pg::InflBlock& b : h->blocks) longest = std::max(longest, b.out_len);
+        const double first_us = 0.3 * (double)longest;
+        if (first_us > 500.0) usleep((useconds_t)first_us);
+    }
     for (;;) {
         const hipError_t q = hipEventQuery(h->done);
         if (q == hipSuccess) break;
         if (q != hipErrorNotReady) return ifail(h, PG_ERR_HIP, "hipEventQuery failed: %s", hipGetErrorString(q));
-        usleep(1000);
+        usleep(500);
     }
     PG_IHIP(h, hipMemcpyAsync(h->h_out + n_prefix, h->d_out.p, total, hipMemcpyDeviceToHost, h->stream));
     PG_IHIP(h, hipMemcpyAsync(h->h_status, h->d_status.p, (size_t)nb * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
