@@ -183,6 +183,14 @@ def mapReadPy(bytes read, bytes sequence):
         free(h)
 
 
+def openDevice(int maxReadLength=0):
+    """Create the device context now rather than at the first call that needs it (a caller that has to wait for its
+    input anyway creates it meanwhile)."""
+    if maxReadLength > 0:
+        ensureReadLength(maxReadLength)
+    deviceContext()
+
+
 def closeDevice():
     """Release the device context (tests; a worker process just exits)."""
     global g_ctx, g_table, g_ge, g_np

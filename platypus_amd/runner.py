@@ -142,6 +142,9 @@ def call_chunks(chunks, args, tmpdir):
             return pool.submit(load, unit, [pool.submit(load_piece, unit, j, parts) for j in range(parts)])
 
         pending = collections.deque(submit(k, u) for k, u in enumerate(units[:ahead]))
+        if units and not args.printVarsAndExit:
+            from platypus_amd import calign
+            calign.openDevice(int(opts.rlen))             # while the helpers read the first stretch
         for i, (ch, s, e) in enumerate(units):
             t0 = time.perf_counter()
             bufs, cands = pending.popleft().result()
