@@ -117,7 +117,7 @@ class BamReader(object):
         if not os.path.exists(index) and os.path.exists(fileName[:-4] + ".bai"):
             index = fileName[:-4] + ".bai"
         if os.path.exists(index):
-            self.linear = _read_linear_index(index)
+            self.linear = _linear_index_of(index)
 
     def close(self):
         self.f.close()
@@ -279,6 +279,20 @@ def fetch_split(path, chrom, start, end, parts, inflater=None):
     with ThreadPoolExecutor(parts) as pool:
         got = [a for a in pool.map(piece, range(parts)) if len(a["pos"])]
     return _concat(got)
+
+
+_INDEX_CACHE = {}
+
+
+def _linear_index_of(path):
+    """the linear index of a .bai file, parsed once per process and file state (every helper thread opens readers of
+    its own; the arrays are only read)"""
+    st = os.stat(path)
+    key = (os.path.abspath(path), st.st_mtime_ns, st.st_size)
+    got = _INDEX_CACHE.get(key)
+    if got is None:
+        got = _INDEX_CACHE[key] = _read_linear_index(path)
+    return got
 
 
 def _read_linear_index(path):
