@@ -118,3 +118,45 @@ def test_bam_stretch_through_the_device_inflater(tmp_path):
         assert np.array_equal(split[k], whole[k]), k
     for r in (host, dev, pooled):
         r.close()
+    # without an index the reader scans from the first record: same records through the device inflater
+    import os
+    import shutil
+    bare = str(tmp_path / "bare.bam")
+    shutil.copy(path, bare)
+    assert not os.path.exists(bare + ".bai")
+    r1, r2 = bamio.BamReader(bare), bamio.BamReader(bare, inflater=pool)
+    assert r2.linear is None
+    a, b = r1.fetch(b"sim", 120000, 121000), r2.fetch(b"sim", 120000, 121000)
+    assert len(a["pos"]) > 0
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    r1.close()
+    r2.close()
+
+
+def test_device_inflater_reads_a_file_written_by_the_reference_library(tmp_path):
+    """a BAM written and indexed by the reference's vendored samtools (its own BGZF writer and compression level):
+    the device inflater and the host library give the same records"""
+    from oracle import samref
+    if not samref.available():
+        pytest.skip("oracle/_ref/libsamref.so not built")
+    from platypus_amd import bamio
+    rng = np.random.default_rng(8)
+    recs = []
+    for i, p in enumerate(np.sort(rng.integers(0, 300000, 6000))):
+        L = int(rng.integers(30, 151))
+        recs.append(dict(tid=0, pos=int(p), mapq=int(rng.integers(0, 61)), flag=int(rng.choice([0, 16, 99, 147])), name=b"q%d" % i,
+                         cigar=np.array([(L << 4) | 0], dtype=np.uint32), seq=bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), L)),
+                         qual=bytes(int(q) for q in rng.integers(2, 41, L)), mtid=0, mpos=int(p) + 200, isize=300,
+                         aux=b"NMC\x01" if i % 2 else b""))
+    path = str(tmp_path / "theirs.bam")
+    samref.write(path, [b"chr1"], [300200], b"@HD\tVN:1.0\tSO:coordinate\n@SQ\tSN:chr1\tLN:300200\n", recs)
+    samref.index_build(path)
+    host, dev = bamio.BamReader(path), bamio.BamReader(path, inflater=bamio.InflaterPool(0, 1))
+    for s, e in [(0, 300200), (100000, 150000), (299000, 300200)]:
+        a, b = host.fetch(b"chr1", s, e), dev.fetch(b"chr1", s, e)
+        assert len(a["pos"]) > 10
+        for k in a:
+            assert np.array_equal(a[k], b[k]), (s, e, k)
+    host.close()
+    dev.close()
