@@ -333,7 +333,7 @@ def main():
         try:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import time_stream
-            streamed = time_stream.measure(W=n_windows, N=16, pinned=True, device=device, batch=batch, threads=4)
+            streamed = time_stream.measure(W=n_windows, N=48, pinned=True, device=device, batch=batch, threads=4)
             streamed["link_gbps"] = time_stream.link_rate()
             streamed["what"] = ("haplotypes, reads and window blocks uploaded, kernels run, score / anchor / likelihood "
                                 "fetched for every batch; bytes_up / link_gbps is the least a batch can take")
