@@ -1,5 +1,7 @@
 """A whole region call on simulated data: reads with true CIGARs -> candidates -> windows -> haplotypes ->
 ONE alignment launch + ONE genotype/EM launch -> calls.  The truth is known by construction."""
+import os
+
 import numpy as np
 import pytest
 
@@ -198,6 +200,19 @@ def test_command_line_bam_to_vcf(tmp_path):
     lines3 = open(out3).read().splitlines()
     assert [l for l in lines3 if l.startswith("#CHROM")][0].split("\t")[-2:] == ["s0", "s1"]
     assert [l for l in lines3 if not l.startswith("#")] == [l for l in lines if not l.startswith("#")]
+    # this process has opened the GPU, so the runs above started their workers as fresh interpreters; the same command
+    # in a process of its own forks them before anything touches the GPU: the same records
+    import subprocess
+    import sys
+    assert not runner._gpu_untouched()
+    out4 = str(tmp_path / "calls4.vcf")
+    cmd = [sys.executable, "-m", "platypus_amd.runner", "callVariants", "--bamFiles", ",".join(bams), "--refFile", str(fa),
+           "--regions", "sim:1-%d" % (G - 1), "--output", out4, "--processRegionSize", "10000", "--bufferSize", "10000",
+           "--maxReadLength", "100", "--workersPerGPU", "3"]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    done = subprocess.run(cmd, cwd=root, timeout=100, capture_output=True, text=True)
+    assert done.returncode == 0, done.stderr[-2000:]
+    assert [l for l in open(out4).read().splitlines() if not l.startswith("#")] == [l for l in lines if not l.startswith("#")]
 
 
 def test_print_candidates_and_exit(tmp_path, capsys):
