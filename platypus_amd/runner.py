@@ -245,8 +245,8 @@ def main(argv=None):
                          "four host processes share a GPU, by the host library beyond (measured on 16 cores per GPU: with eight "
                          "processes their inflater streams take turns on the device and the cores are there to be used)")
     ap.add_argument("--inflaters", type=int, default=None,
-                    help="device inflaters of a host process, shared by its helper threads (default: 4 for a single process, "
-                         "2 per process otherwise)")
+                    help="device inflaters of a host process, shared by its helper threads (default: 4 with up to three "
+                         "processes per GPU, 3 with four, 2 beyond)")
     ap.add_argument("--nCPU", type=int, default=None,
                     help="the reference's option: taken as the total number of host processes when --workersPerGPU is not given")
     ap.add_argument("--labels", default=None, help="regular expression that extracts a sample name from a BAM path")
@@ -280,7 +280,7 @@ def main(argv=None):
     if args.readAhead is None:
         args.readAhead = 12 if n_workers == 1 else 6
     if args.inflaters is None:
-        args.inflaters = 4 if n_workers == 1 else 2
+        args.inflaters = max(2, min(4, 12 // max(1, args.workersPerGPU)))     # twelve streams per GPU between its processes
     if args.inflate == "auto":
         args.inflate = "device" if max(1, args.workersPerGPU) <= 4 else "host"
     weights = None

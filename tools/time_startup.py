@@ -5,6 +5,8 @@ included; a least-squares line through (length, seconds) gives the seconds a run
 the rate it calls at from then on.
 
     python tools/time_startup.py [workers ...]        (default 1 4)
+
+TS_SIZES="32 64" limits the region lengths (Mb), TS_ARGS adds runner arguments (several sets separated by ';': each is timed).
 """
 import multiprocessing
 import os
@@ -40,12 +42,15 @@ def main():
         bamio.write_bam(bam, [(b"sim", G)], reads, sample="S")
         out = os.path.join(work, "calls.vcf")
         print("data set written", flush=True)
-        for workers in workers_list:
+        sizes = [int(x) for x in os.environ.get("TS_SIZES", "1 8 16 32 64").split()]
+        for workers, extra in [(w, e.split()) for w in workers_list for e in os.environ.get("TS_ARGS", "").split(";")]:
+            if extra:
+                print("runner arguments: %s" % " ".join(extra), flush=True)
             xs, ys = [], []
-            for mb in (1, 8, 16, 32, 64):
+            for mb in sizes:
                 L = mb * 1000000
                 args = ["callVariants", "--bamFiles", bam, "--refFile", fa, "--regions", "sim:1-%d" % (L - 1), "--output", out,
-                        "--maxReadLength", "150"]
+                        "--maxReadLength", "150"] + extra
                 if workers > 1:
                     args += ["--workersPerGPU", str(workers), "--processRegionSize", str(max(1000000, L // workers))]
                 best = 1e30
@@ -60,6 +65,8 @@ def main():
                 xs.append(mb)
                 ys.append(best)
                 print("workers %d  %3d Mb  %.3f s  (%.0f Mbp/min)" % (workers, mb, best, mb / best * 60), flush=True)
+            if len(xs) < 3:
+                continue
             slope, icpt = np.polyfit(xs[1:], ys[1:], 1)
             print("workers %d: %.3f s before the first base, then %.4f s per Mb = %.0f Mbp/min" % (workers, icpt, slope, 60.0 / slope),
                   flush=True)
