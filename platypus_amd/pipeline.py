@@ -492,6 +492,12 @@ def callRegion(chrom, start, end, readBuffers, refFile, options=None, variants=N
         win_filters = sorted(set(win_flags))
         readCounts = batch.readCounts(k)
         idxOf = {id(hap): h for h, hap in enumerate(haplotypes)}
+        # The NR column is a local that only a position with ONE variant assigns (variantcaller.pyx:422-423) and every
+        # called individual's column reads (:436): at a position with several variants it still holds what the last
+        # position with one variant left in it -- the window's read count of the last individual called there -- and
+        # when there has been none the reference fails, logs and gives up the rest of the window (:189-191).
+        lastCount = None
+        windowLost = False
         for pos in sorted(byPos):
             entries = byPos[pos]
             if len(entries) > 1:
@@ -527,7 +533,17 @@ def callRegion(chrom, start, end, readBuffers, refFile, options=None, variants=N
                 c.GT.append("%d/%d" % (a, b))
                 c.GQ.append(int(-10.0 * math.log10(max(1e-10, 1.0 - pop.genotypeLikelihoods[ind]))))
                 c.GL.append([-1, -1, -1])
-                c.nReads.append(readCounts[ind])
+                if len(vs) == 1:
+                    lastCount = readCounts[ind]
+                elif lastCount is None:
+                    windowLost = True
+                    break
+                c.nReads.append(lastCount)
+            if windowLost:
+                logger.warning("Window %s:%d-%d: nothing from %d on is written: the read count of a position with several "
+                               "variants is not defined before a position with one", chrom.decode(), windows[i]["startPos"],
+                               windows[i]["endPos"], pos + 1)
+                break
             if len(vs) == 1:                                          # GL of AA/AB/BB: variantcaller.pyx:371-378,419-429
                 # The reference builds a fresh reference haplotype and a fresh haplotype with this variant over the
                 # window haplotypes' span: the same sequences as the window's own first haplotype and its haplotype

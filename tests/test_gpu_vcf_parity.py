@@ -30,6 +30,51 @@ def test_region_vcf_lines_equal_the_restatement(kw):
     assert not diffs, {k: v[:3] for k, v in diffs.items()}
 
 
+def _three_sample_window(first_single):
+    """three samples at different coverage around one window: a six-base deletion (first sample, when first_single), and
+    inside its span a SNP (second sample) and an insertion (third sample) at ONE position"""
+    from platypus_amd import simulate
+    rng = np.random.default_rng(41)
+    G = 6000
+    genome = simulate.random_genome(rng, G)
+    p = 3000
+    while len(set(genome[p - 2:p + 12])) < 4 or genome[p + 4:p + 5] == b"A":   # no repeat to shift the indels in
+        p += 1
+    dele = (p, genome[p + 1:p + 7], b"", 2)
+    snp = (p + 4, genome[p + 4:p + 5], b"A", 2)
+    ins = (p + 4, b"", b"GTC" if genome[p + 5:p + 6] != b"G" else b"CTG", 2)
+    bufs = []
+    for mine, cov in (([dele] if first_single else [], 18), ([snp], 30), ([ins], 44)):
+        reads = simulate.simulate_reads(rng, genome, mine, coverage=cov, read_len=100, error_rate=0.0)
+        bufs.append(simulate.buffer_of(reads, 0, G))
+    return genome, bufs, p
+
+
+def test_read_count_column_at_a_position_with_several_variants():
+    """variantcaller.pyx:422-423,436: the NR column is a local that only a position with one variant assigns.  At a
+    position with two variants every called individual shows what the last such position left there (the last
+    individual's count); without one before it the reference fails there and the rest of the window is never written
+    (:189-191).  Product and restatement do the same."""
+    from platypus_amd import calign, pipeline
+    opts = pipeline.Options(rlen=100, minPosterior=0)
+    genome, bufs, p = _three_sample_window(first_single=True)
+    got, want, skipped = vc.call_both(b"sim", 0, len(genome), bufs, genome, opts)
+    assert not skipped and got == want
+    rows = [l.split("\t") for l in got]
+    assert len(rows) == 2
+    single, double = rows
+    assert "," not in single[4] and "," in double[4] and int(double[1]) == p + 5
+    own = [c.split(":")[3] for c in single[9:]]
+    assert len(set(own)) == 3                                            # three individuals, three read counts
+    assert [c.split(":")[3] for c in double[9:]] == [own[-1]] * 3        # ... and the last one's in every column after it
+    # nothing with one variant before the position with two: the window is lost from there on
+    genome, bufs, p = _three_sample_window(first_single=False)
+    got, want, skipped = vc.call_both(b"sim", 0, len(genome), bufs, genome, opts)
+    calign.closeDevice()
+    assert len(skipped) == 1 and "nReadsThisIndividual" in str(skipped[0][2])
+    assert got == want == []
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("inflate", ["device", "host"])
 def test_file_to_file_run_equals_the_restatements_end_to_end(tmp_path, inflate):

@@ -8,5 +8,7 @@ checks=${@:-parity caller vcf pipeline inflate}
 out=gpurun_out/$tag; mkdir -p $out
 for f in $checks; do
   timeout -k 10 $((secs + 120)) python3 -u tests/fuzz_$f.py $secs $seed > $out/fuzz_$f.txt 2>&1
-  echo "fuzz_$f rc=$?"; tail -2 $out/fuzz_$f.txt
+  rc=$?
+  echo "fuzz_$f rc=$rc"; tail -2 $out/fuzz_$f.txt
+  if [ $rc -ne 0 ]; then exit $rc; fi          # nothing more on the GPU after a check that failed or was killed
 done
