@@ -114,11 +114,8 @@ def parseRecords(const unsigned char[::1] data, int refID, int start, int end):
             vmp[i] = mpos
             q = p + 36 + lname
             for k in range(ncig):
-                memcpy(&cw, &data[q + 4 * k], 4)
-                op = cw & 0xf
-                if op == 7 or op == 8:                      # '=' and 'X' are matches to this caller
-                    cw = (cw & 0xfffffff0u)
-                vc[c + k] = cw
+                memcpy(&cw, &data[q + 4 * k], 4)            # '=' and 'X' stay what they are: to the reference they are
+                vc[c + k] = cw                              # "other kinds of flag" that move nothing (variant.pyx:472-474)
             c += ncig
             vco[i + 1] = c
             q += 4 * ncig

@@ -70,8 +70,8 @@ def _harden(rng, reads, genome_len):
 
 
 def _clip_some(rng, reads):
-    """turns the first bases of some reads' leading match into a soft clip (the position moves along), and puts a hard
-    clip in front of others"""
+    """turns the first bases of some reads' leading match into a soft clip (the position moves along), puts a hard
+    clip in front of others, and writes the matches of others with '=' and 'X' operations"""
     coff, cig = reads["cigarOff"], list(reads["cigar"])
     pos = reads["pos"].copy()
     new, new_off = [], [0]
@@ -84,6 +84,10 @@ def _clip_some(rng, reads):
             pos[i] += k
         elif r < 0.08:
             ops = [(5 << 4) | 5] + ops
+        elif r < 0.10:                                                # every match written as '=': nothing moves for those
+            ops = [(w & ~0xf) | 7 if (w & 0xf) == 0 else w for w in ops]      # (variant.pyx:472-474), and the read has no extent
+        elif r < 0.12 and (ops[0] & 0xf) == 0 and (ops[0] >> 4) > 12:  # '=', 'X', then the rest of the match
+            ops = [(5 << 4) | 7, (1 << 4) | 8, (((ops[0] >> 4) - 6) << 4) | 0] + ops[1:]
         new.extend(ops)
         new_off.append(len(new))
     out = dict(reads)
