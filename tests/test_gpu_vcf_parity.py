@@ -81,46 +81,7 @@ def test_file_to_file_run_equals_the_restatements_end_to_end(tmp_path, inflate):
     """BAM + FASTA files in, VCF file out through platypus_amd.runner (BGZF blocks inflated on the GPU or by the host
     library, device kernels), against the CPU restatements chained from the records on: buffer filtering and trimming and
     candidates (oracle/candidates_oracle.py), windows to VCF text (oracle/vcf_oracle.py).  Byte-identical body lines."""
-    from oracle import candidates_oracle as co, vcf_oracle as vo
-    from platypus_amd import bamio, pipeline, runner, simulate
-    rng = np.random.default_rng(31)
-    G, unit, rlen = 90000, 15000, 100
-    genome = simulate.random_genome(rng, G, homopolymers=30)
-    truth = simulate.plant_variants(rng, genome, 110, spacing=300, indel_frac=0.4)
-    fa = tmp_path / "ref.fa"
-    fa.write_bytes(b">sim\n" + b"\n".join(genome[i:i + 60] for i in range(0, G, 60)) + b"\n")
-    (tmp_path / "ref.fa.fai").write_bytes(b"sim\t%d\t5\t60\t61\n" % G)
-    bams = []
-    for k in range(2):
-        mine = [t for t in truth if rng.random() < 0.75]
-        reads = simulate.simulate_reads(rng, genome, mine, coverage=18, read_len=rlen, paired=True, insert=(280, 40), error_rate=0.008)
-        path = str(tmp_path / ("s%d.bam" % k))
-        bamio.write_bam(path, [(b"sim", G)], reads, sample="S%d" % k)
-        bams.append(path)
-    out = str(tmp_path / "calls.vcf")
-    start, end = 1000, G - 1000
-    rc = runner.main(["callVariants", "--bamFiles", ",".join(bams), "--refFile", str(fa), "--regions", "sim:%d-%d" % (start, end),
-                      "--output", out, "--processRegionSize", "45000", "--bufferSize", str(unit), "--maxReadLength", str(rlen),
-                      "--inflate", inflate])
-    assert rc == 0
-    got = [l for l in open(out).read().splitlines() if not l.startswith("#")]
-    # the restatements over the same chunks and read buffers (runner.py: chunks of processRegionSize, buffers of bufferSize)
-    opts = pipeline.Options(rlen=rlen)
-    ref = vo.Ref({b"sim": genome})
-    want, skipped = [], []
-    readers = [bamio.BamReader(b) for b in bams]
-    from platypus_amd import shard
-    for ch in shard.split_regions([("sim", start, end)], 45000):
-        for s in range(ch[1], ch[2], unit):
-            e = min(s + unit, ch[2])
-            kept = [co.buffer_reads(co.create_reads(r.fetch(b"sim", s, e)), opts.minMapQual, int(opts.maxReads),
-                                    opts.minGoodQualBases, opts.maxBadQualBases) for r in readers]
-            cands = co.candidates_in_region(b"sim", s, e, kept, ref, opts)
-            samples = [vo.Reads([r["pos"] for r in k], [r["end"] for r in k], [r["mapq"] for r in k], [r["isReverse"] for r in k],
-                                [r["seq"] for r in k], [bytes(r["qual"]) for r in k]) for k in kept]
-            want.extend(vo.call_region(b"sim", s, e, cands, samples, ref, opts, skipped=skipped))
-    for r in readers:
-        r.close()
+    got, want, skipped = vc.files_both(str(tmp_path), 31, inflate=inflate)
     assert not skipped
     assert len(want) > 80
     diff = vc.classify(got, want)

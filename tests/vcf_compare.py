@@ -81,3 +81,55 @@ def simulated_region(seed, G=12000, n_var=40, coverage=30, read_len=100, n_sampl
         reads = simulate.simulate_reads(rng, g, mine, coverage=coverage, read_len=read_len, error_rate=error_rate, **kw)
         bufs.append(simulate.buffer_of(reads, 0, G))
     return genome, truth, bufs
+
+
+def files_both(work, seed, inflate="device", G=90000, unit=15000, rlen=100, n_var=110, spacing=300, indel_frac=0.4,
+               coverage=18, paired=True, error_rate=0.008, n_samples=2, chunk=45000, homopolymers=30, options=()):
+    """BAM + FASTA files written under `work` and called to a VCF file by platypus_amd.runner (device kernels; BGZF
+    blocks inflated as `inflate` says), and the same files through the CPU restatements chained from the records on
+    (oracle/candidates_oracle.py, oracle/vcf_oracle.py) over the same chunks and read buffers.  `options`: pairs of
+    (runner argument name, value) that both sides get.  Returns (product body lines, restatement lines, windows the
+    restatement skipped)."""
+    import os
+    from oracle import candidates_oracle as co, vcf_oracle as vo
+    from platypus_amd import bamio, pipeline, runner, shard, simulate
+    rng = np.random.default_rng(seed)
+    genome = simulate.random_genome(rng, G, homopolymers=homopolymers)
+    truth = simulate.plant_variants(rng, genome, n_var, spacing=spacing, indel_frac=indel_frac)
+    fa = os.path.join(work, "ref.fa")
+    with open(fa, "wb") as f:
+        f.write(b">sim\n" + b"\n".join(genome[i:i + 60] for i in range(0, G, 60)) + b"\n")
+    with open(fa + ".fai", "wb") as f:
+        f.write(b"sim\t%d\t5\t60\t61\n" % G)
+    bams = []
+    for k in range(n_samples):
+        mine = [t for t in truth if rng.random() < 0.75]
+        kw = dict(paired=True, insert=(int(2.8 * rlen), 40)) if paired else {}
+        reads = simulate.simulate_reads(rng, genome, mine, coverage=coverage, read_len=rlen, error_rate=error_rate, **kw)
+        path = os.path.join(work, "s%d.bam" % k)
+        bamio.write_bam(path, [(b"sim", G)], reads, sample="S%d" % k)
+        bams.append(path)
+    out = os.path.join(work, "calls.vcf")
+    start, end = 1000, G - 1000
+    extra = [x for name, value in options for x in ("--" + name, str(value))]
+    rc = runner.main(["callVariants", "--bamFiles", ",".join(bams), "--refFile", fa, "--regions", "sim:%d-%d" % (start, end),
+                      "--output", out, "--processRegionSize", str(chunk), "--bufferSize", str(unit), "--maxReadLength", str(rlen),
+                      "--inflate", inflate] + extra)
+    assert rc == 0
+    got = [l for l in open(out).read().splitlines() if not l.startswith("#")]
+    opts = pipeline.Options(rlen=rlen, **dict(options))
+    ref = vo.Ref({b"sim": genome})
+    want, skipped = [], []
+    readers = [bamio.BamReader(b) for b in bams]
+    for ch in shard.split_regions([("sim", start, end)], chunk):
+        for s in range(ch[1], ch[2], unit):
+            e = min(s + unit, ch[2])
+            kept = [co.buffer_reads(co.create_reads(r.fetch(b"sim", s, e)), opts.minMapQual, int(opts.maxReads),
+                                    opts.minGoodQualBases, opts.maxBadQualBases) for r in readers]
+            cands = co.candidates_in_region(b"sim", s, e, kept, ref, opts)
+            samples = [vo.Reads([r["pos"] for r in k], [r["end"] for r in k], [r["mapq"] for r in k], [r["isReverse"] for r in k],
+                                [r["seq"] for r in k], [bytes(r["qual"]) for r in k]) for k in kept]
+            want.extend(vo.call_region(b"sim", s, e, cands, samples, ref, opts, skipped=skipped))
+    for r in readers:
+        r.close()
+    return got, want, skipped
