@@ -271,7 +271,9 @@ def fetch_split(path, chrom, start, end, parts, inflater=None):
     def piece(k):
         r = BamReader(path, inflater=inflater)
         try:
-            a = r.fetch(chrom, edges[k], edges[k + 1])
+            # from one base before the edge: a record without extent on the reference (no M, D or N operation: its end
+            # is its position) that starts on the edge overlaps [edge - 1, ...) only
+            a = r.fetch(chrom, edges[k] - (1 if k else 0), edges[k + 1])
         finally:
             r.close()
         return a if k == 0 else drop_before(a, edges[k])

@@ -1453,13 +1453,55 @@ __global__ __launch_bounds__(64) void k_var_post(const WinDesc* __restrict__ win
         fp[k] = m[k] ? 0.0 : fk;
         part += fp[k];
     }
-    const double sum_freqs = wave_sum(part);
+    // The windows em_is_exact names get every sum in the reference's own order (:554-627), one individual per lane:
+    // variants whose inputs are equal then have exactly equal posteriors, and the ranking by posterior
+    // (variantcaller.pyx:157-165) breaks their ties the way the reference does.
+    const bool exact = em_is_exact(n, W.n_ind, W.n_gen);
+    double sum_freqs = wave_sum(part);
     __builtin_amdgcn_wave_barrier();
+    if (exact) {
+        sum_freqs = 0.0;
+        for (int k = 0; k < n; ++k)
+            if (!m[k]) sum_freqs = __dadd_rn(sum_freqs, f[k]);
+    }
     if (sum_freqs > 0)
         for (int k = lane; k < n; k += 64)
             if (fp[k] != 0.0) fp[k] /= sum_freqs;
     __builtin_amdgcn_wave_barrier();
     double slp_var = 0.0, slp_novar = 0.0;
+    if (exact) {
+        for (int i0 = 0; i0 < W.n_ind; i0 += 64) {
+            const int i = i0 + lane;
+            double lv = 0.0, ln = 0.0;
+            int has = 0;
+            if (i < W.n_ind && io[i + 1] != io[i]) {                         // :590-591
+                has = 1;
+                const double* P = full + W.full_base + (int64_t)i * n * W.ld;
+                double pv = 0.0, pn = 0.0;
+                for (int r = 0; r < n; ++r)
+                    for (int q = r; q < n; ++q) {                            // :597-614, genotype by genotype
+                        const double g = P[(int64_t)r * W.ld + q];
+                        const double fac = r != q ? 2.0 : 1.0;
+                        pv = __dadd_rn(pv, __dmul_rn(__dmul_rn(__dmul_rn(fac, f[r]), f[q]), g));
+                        pn = __dadd_rn(pn, __dmul_rn(__dmul_rn(__dmul_rn(fac, fp[r]), fp[q]), g));
+                    }
+                lv = pv > 0 ? log(pv) : -708.0;                              // :616-624
+                ln = pn > 0 ? log(pn) : -708.0;
+            }
+            const int here = min(64, W.n_ind - i0);
+            for (int j = 0; j < here; ++j) {                                 // added up in the individuals' order
+                const int hj = __shfl(has, j);
+                const double a = __shfl(lv, j), b = __shfl(ln, j);
+                if (hj) { slp_var = __dadd_rn(slp_var, a); slp_novar = __dadd_rn(slp_novar, b); }
+            }
+        }
+        if (lane == 0) {
+            const double ratio = exp(slp_novar - slp_var);                   // :626-627
+            const double pr = prior[v];
+            out[v] = pr / (pr + ratio * (1.0 - pr));
+        }
+        return;
+    }
     for (int i = 0; i < W.n_ind; ++i) {
         if (io[i + 1] == io[i]) continue;                                    // :590-591
         const double* P = full + W.full_base + (int64_t)i * n * W.ld;

@@ -85,7 +85,7 @@ def call_chunks(chunks, args, tmpdir):
         out = []
         for r in local.piece_readers:
             try:
-                a = r.fetch(chrom, lo, hi)
+                a = r.fetch(chrom, lo - (1 if k else 0), hi)      # (a record without extent that starts on the edge)
             except KeyError:
                 a = bamio._concat([])
             out.append(a if k == 0 else bamio.drop_before(a, lo))

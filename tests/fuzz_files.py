@@ -4,7 +4,8 @@
     python tests/fuzz_files.py [seconds] [first_seed]
 
 Every run draws its own reference length, variant density and mix, coverage, read length, error rate, single or paired
-reads, one to three BAM files, chunk and buffer lengths, where the BGZF blocks are inflated and a few caller options,
+reads (half of the runs with hardened records: duplicates, clips, bad qualities, '='/'X' operations ...), one to three
+BAM files, chunk and buffer lengths, where the BGZF blocks are inflated and a few caller options,
 writes BAM + FASTA files, calls them with platypus_amd.runner (device kernels) and with the chained CPU restatements
 (oracle/candidates_oracle.py, oracle/vcf_oracle.py), and compares the VCF body lines as text.  Exit status 1 if any
 line differs."""
@@ -45,7 +46,7 @@ def main():
                   indel_frac=float(rng.choice([0.1, 0.3, 0.6])), coverage=int(rng.integers(8, 40)),
                   paired=bool(rng.random() < 0.5), error_rate=float(rng.choice([0.0, 0.003, 0.01, 0.02])),
                   n_samples=int(rng.integers(1, 4)), chunk=int(rng.choice([unit, 3 * unit, 200000])),
-                  homopolymers=int(rng.choice([0, 30])), options=tuple(options))
+                  homopolymers=int(rng.choice([0, 30])), options=tuple(options), harden=bool(rng.random() < 0.5))
         work = tempfile.mkdtemp(prefix="platypus_amd_fuzz_")
         try:
             got, want, skipped = vc.files_both(work, seed, **kw)

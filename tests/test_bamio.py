@@ -154,3 +154,33 @@ def test_region_bytes_follow_coverage(tmp_path):
     a, b = r.regionBytes("sim", 0, 196608), r.regionBytes("sim", 212992, 399999)
     assert a > 0 and 2.2 < b / a < 3.8
     assert r.regionBytes("nope", 0, 10) is None
+
+
+def test_pieces_keep_records_without_extent_on_their_edges(tmp_path):
+    """records without an M, D or N operation (all '=' or all soft clip: their end is their position,
+    samtoolsWrapper.pyx:773-774) and records without CIGAR that start exactly where a piece starts: the stretch read in
+    pieces holds what the stretch read at once holds"""
+    rng = np.random.default_rng(77)
+    G = 8000
+    genome = simulate.random_genome(rng, G)
+    reads = simulate.simulate_reads(rng, genome, [], coverage=80, read_len=50)
+    s, e, parts = 1000, 6000, 12
+    edges = [s + (e - s) * k // parts for k in range(parts + 1)]
+    coff, cig = reads["cigarOff"], reads["cigar"].copy()
+    changed = 0
+    for i in np.flatnonzero(np.isin(reads["pos"], edges)):
+        if coff[i + 1] - coff[i] == 1:
+            cig[coff[i]] = (cig[coff[i]] & ~np.uint32(0xf)) | np.uint32(7 if changed % 2 else 4)
+            changed += 1
+    assert changed > 6
+    path = str(tmp_path / "edges.bam")
+    bamio.write_bam(path, [(b"sim", G)], dict(reads, cigar=cig), sample="E")
+    rd = bamio.BamReader(path)
+    want = rd.fetch(b"sim", s, e)
+    rd.close()
+    got = bamio.fetch_split(path, b"sim", s, e, parts)
+    for k in want:
+        assert np.array_equal(got[k], want[k]), k
+    on_edges = np.isin(want["pos"], edges[1:-1])
+    ops = want["cigar"][want["cigarOff"][:-1][on_edges]] & 0xf
+    assert ((ops == 7) | (ops == 4)).sum() >= 8                         # (those on the stretch's own start and end are outside it)

@@ -87,3 +87,19 @@ def test_file_to_file_run_equals_the_restatements_end_to_end(tmp_path, inflate):
     diff = vc.classify(got, want)
     assert not diff, {k: v[:3] for k, v in diff.items()}
     assert got == want
+
+
+def test_equal_posteriors_stay_equal_in_the_ranking_of_a_crowded_window(tmp_path):
+    """a window with more candidates than maxVariants keeps the ones with the highest posteriors (variantcaller.pyx:142-166);
+    here four SNPs with two supporting reads each stand beside a deletion with exactly equal inputs, their posteriors are
+    equal to the last bit in the reference's arithmetic, and the tie goes by position.  The device adds the posterior's
+    sums in the reference's order for such windows, so the same three variants survive (a run tests/fuzz_files.py found:
+    hardened records, two samples, maxVariants 3)."""
+    kw = dict(inflate="device", G=80794, unit=5000, rlen=100, n_var=373, spacing=40, indel_frac=0.6, coverage=30, paired=True,
+              error_rate=0.02, n_samples=2, chunk=5000, homopolymers=0, options=(("minPosterior", 20), ("maxVariants", 3)),
+              harden=True)
+    got, want, skipped = vc.files_both(str(tmp_path), 582, **kw)
+    assert len(want) > 300
+    diff = vc.classify(got, want)
+    assert not diff, {k: v[:3] for k, v in diff.items()}
+    assert got == want

@@ -84,11 +84,14 @@ def simulated_region(seed, G=12000, n_var=40, coverage=30, read_len=100, n_sampl
 
 
 def files_both(work, seed, inflate="device", G=90000, unit=15000, rlen=100, n_var=110, spacing=300, indel_frac=0.4,
-               coverage=18, paired=True, error_rate=0.008, n_samples=2, chunk=45000, homopolymers=30, options=()):
+               coverage=18, paired=True, error_rate=0.008, n_samples=2, chunk=45000, homopolymers=30, options=(),
+               harden=False):
     """BAM + FASTA files written under `work` and called to a VCF file by platypus_amd.runner (device kernels; BGZF
     blocks inflated as `inflate` says), and the same files through the CPU restatements chained from the records on
     (oracle/candidates_oracle.py, oracle/vcf_oracle.py) over the same chunks and read buffers.  `options`: pairs of
-    (runner argument name, value) that both sides get.  Returns (product body lines, restatement lines, windows the
+    (runner argument name, value) that both sides get.  harden: the simulated records get duplicates, unmapped and
+    low-quality records, short fragments, bad heads and tails, 'N's, soft and hard clips and '='/'X' operations
+    (tests/test_candidates_oracle.py) before they are written.  Returns (product body lines, restatement lines, windows the
     restatement skipped)."""
     import os
     from oracle import candidates_oracle as co, vcf_oracle as vo
@@ -106,6 +109,9 @@ def files_both(work, seed, inflate="device", G=90000, unit=15000, rlen=100, n_va
         mine = [t for t in truth if rng.random() < 0.75]
         kw = dict(paired=True, insert=(int(2.8 * rlen), 40)) if paired else {}
         reads = simulate.simulate_reads(rng, genome, mine, coverage=coverage, read_len=rlen, error_rate=error_rate, **kw)
+        if harden:
+            from tests.test_candidates_oracle import _clip_some, _harden
+            reads = _clip_some(rng, _harden(rng, reads, G))
         path = os.path.join(work, "s%d.bam" % k)
         bamio.write_bam(path, [(b"sim", G)], reads, sample="S%d" % k)
         bams.append(path)
