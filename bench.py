@@ -177,7 +177,18 @@ def main():
 
     from platypus_amd import shard
     rank, world, local_rank = shard.rank_info()
-    import torch
+    import torch                                           # (before the caller's library is loaded: torch brings a HIP runtime of its own)
+    # ---- file to file (simulated BAM + FASTA -> VCF through the region caller), not part of the metric:
+    # the second figure BASELINE.json names, Mbp/min, for ONE process / one GPU.  It runs first, while this process
+    # has not opened the GPU: the caller runs in processes of its own, and a parent that holds streams and memory on
+    # the same device takes a tenth off their rate ------------------------------------------------------
+    e2e = None
+    if world == 1 and not args.no_e2e and args.workload == "wgs":
+        try:
+            e2e = end_to_end_leg()
+        except Exception as e:                             # reported, never hidden
+            e2e = {"error": "%s: %s" % (type(e).__name__, e)}
+
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -339,15 +350,6 @@ def main():
                                 "fetched for every batch; bytes_up / link_gbps is the least a batch can take")
         except Exception as e:                             # reported, never hidden
             streamed = {"error": "%s: %s" % (type(e).__name__, e)}
-
-    # ---- file to file (simulated BAM + FASTA -> VCF through the region caller), not part of the metric:
-    # the second figure BASELINE.json names, Mbp/min, for ONE process / one GPU -------------------------
-    e2e = None
-    if world == 1 and not args.no_e2e and args.workload == "wgs":
-        try:
-            e2e = end_to_end_leg()
-        except Exception as e:                             # reported, never hidden
-            e2e = {"error": "%s: %s" % (type(e).__name__, e)}
 
     # ---- CPU baseline: the reference's own compiled routine on the host cores ---------
     cpu = None

@@ -530,7 +530,8 @@ def call_region(chrom, start, end, variants, samples, ref, opts, skipped=None):
                 if len(vs) > 50:
                     vs = sorted(sorted(vs, key=lambda v: v.nSupportingReads, reverse=True)[:50], key=lambda v: v.order())
                 pre = Population([ref_hap] + [Hap(ref, chrom, ws, we, (v,), opts.rlen) for v in vs], samples, opts)
-                by_post = sorted(((pre.posterior(v), v.order(), i) for i, v in enumerate(vs)), reverse=True)
+                # varsByPost.sort(reverse=True) on (posterior, variant): variants that compare equal keep their order
+                by_post = sorted(((pre.posterior(v), v.order(), i) for i, v in enumerate(vs)), key=lambda t: t[:2], reverse=True)
                 vs = sorted((vs[i] for _, _, i in by_post[:opts.maxVariants]), key=lambda v: v.order())
                 w["variants"] = vs
             var_haps = haplotypes_in_window(w, n_reads, ref, opts)
