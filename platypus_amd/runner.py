@@ -12,14 +12,17 @@ nothing is exchanged between them.  Inside a chunk reads are buffered --bufferSi
 import argparse
 import collections
 import multiprocessing
-import logging
 import os
 import sys
 import tempfile
 import threading
 import time
 
-from platypus_amd import shard
+# Nothing here calls a BLAS routine, and the thread pool numpy's BLAS library starts when it is loaded would make this
+# a process with native threads, whose workers have to be started as fresh interpreters instead of forked
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+
+from platypus_amd import shard  # noqa: E402
 
 
 def parse_regions(text, fasta):
@@ -165,16 +168,16 @@ def call_chunks(chunks, args, tmpdir):
                     print(v)
                 continue
             t0 = time.perf_counter()
-            try:
-                stats = {} if timed else None
-                calls = pipeline.callRegion(chrom.encode(), s, e, bufs, fa, opts, variants=cands, stats=stats)
-                if timed:
-                    for k, v in stats.items():
-                        if k.startswith("t_") or k in ("pack", "upload", "device", "unpack"):
-                            phases[k] = phases.get(k, 0.0) + v
-            except Exception as err:                          # one stretch is lost, the run goes on (variantcaller.pyx:189-191)
-                logging.getLogger("Log").error("No calls for %s:%d-%d: %s: %s", chrom, s, e, type(err).__name__, err)
-                calls = []
+            # A window that cannot be called costs only itself: callRegion skips it with a log line, as the reference does
+            # (variantcaller.pyx:189-191).  Anything else -- a device error, a fault of this code -- ends the worker with a
+            # non-zero status, as the reference's region wrapper re-raises (variantcaller.pyx:238-248): no stretch is ever
+            # dropped from a run that reports success.
+            stats = {} if timed else None
+            calls = pipeline.callRegion(chrom.encode(), s, e, bufs, fa, opts, variants=cands, stats=stats)
+            if timed:
+                for k, v in stats.items():
+                    if k.startswith("t_") or k in ("pack", "upload", "device", "unpack"):
+                        phases[k] = phases.get(k, 0.0) + v
             t1 = time.perf_counter()
             for c in calls:
                 out.write(vcfout.record(c, fa) + "\n")
@@ -205,6 +208,15 @@ def _gpu_untouched():
             except OSError:
                 pass
         return True
+    except OSError:
+        return False
+
+
+def _single_threaded():
+    """True when the process has one thread in all, native threads of loaded libraries included (threading's own count
+    sees interpreter threads only); a process that cannot tell says no"""
+    try:
+        return len(os.listdir("/proc/self/task")) == 1
     except OSError:
         return False
 
@@ -299,7 +311,7 @@ def main(argv=None):
     else:
         # Workers are forked while this process has not opened the GPU (no second interpreter start-up and import); a
         # process that has, or that runs other threads, starts them fresh: nothing of its GPU state may reach them.
-        forked = _gpu_untouched() and threading.active_count() == 1
+        forked = _gpu_untouched() and _single_threaded()
         ctx = multiprocessing.get_context("fork" if forked else "spawn")
         queue = ctx.Queue()
         procs = [ctx.Process(target=_worker, args=(r, per_rank[r], args, tmpdir, queue, forked)) for r in range(n_workers)]
