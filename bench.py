@@ -1,24 +1,39 @@
 #!/usr/bin/env python
 """Benchmark of the read x haplotype alignment hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--windows NW]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--windows NW] [--workload wgs|panel|joint]
 
 A *step* is one pass of the whole hot path (7-mer anchoring of pairs on
 indel-bearing haplotypes, banded DP, likelihood) over one synthetic batch that
 is already resident in HBM.  The workload is the pair stream of BASELINE.json's
 configs[1] (single-sample 30x WGS, 150-bp reads): windows of 4 candidate
 haplotypes (~750 bp) x 32 overlapping reads, 2^22 pairs per GPU by default.
-With N > 1 every rank owns its own shard of windows (different seed), nothing
-is exchanged on the data path, and the value is all ranks' cells over the
-slowest rank's time (weak scaling).
 
-Prints ONE JSON line on rank 0.
+Ranks.  The path shards by independent genomic regions, so N GPUs are N
+processes that exchange nothing on the data path (weak scaling): every rank
+owns its own shard of windows (seed + rank) on its own device, the value is all
+ranks' cells over the slowest rank's time.  `--gpus N` started plainly launches
+the N ranks itself: the parent touches no GPU, starts N fresh interpreters (one
+per device, rank k on device k mod the number of devices), lines them up on a
+barrier before and after the K timed steps and prints ONE JSON line.  Started
+under `python -m torch.distributed.run` (RANK / WORLD_SIZE in the environment)
+the given ranks are used instead and the barrier and the MAX over ranks go
+through a gloo process group; nothing of torch touches the GPU in either mode,
+and without a launcher torch is not imported at all.
+
+The second figure BASELINE.json names, Mbp/min from files to a VCF, is the
+`end_to_end` object: a simulated 30x BAM + FASTA called by platypus_amd.runner,
+at N > 1 with `--nGPU N`, the merged VCF compared byte for byte with the
+one-process run's.
 """
 import argparse
 import json
 import os
 import sys
 import time
+
+# nothing here calls a BLAS routine: without its thread pool the runner's workers can be forked (see runner.py)
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -73,167 +88,25 @@ def pmc_traffic(n_pairs, read_len):
     return (2.0 * val["FETCH_SIZE"] + val["WRITE_SIZE"]) * 1024.0, os.path.relpath(files[-1], ROOT)
 
 
-def end_to_end_leg(kb=2000, coverage=30, copies=32):
-    """Simulate kb kilobases at the given coverage (one planted variant per kb, 150-bp read pairs from 500 +- 50 bp
-    fragments with true CIGARs),
-    lay `copies` repeats of them end to end as one reference (simulating is far slower than calling),
-    write BAM + .bai and FASTA + .fai, call them to a VCF with platypus_amd.runner, time the call."""
-    import multiprocessing
-    import shutil
-    import tempfile
-    from platypus_amd import bamio, runner, simulate
-    rng = np.random.default_rng(5)
-    G = kb * 1000
-    work = tempfile.mkdtemp(prefix="platypus_amd_bench_")
-    try:
-        genome = simulate.random_genome(rng, G)
-        truth = simulate.plant_variants(rng, genome, G // 1000, spacing=600)
-        reads = simulate.simulate_reads(rng, genome, truth, coverage=coverage, read_len=150, paired=True, insert=(500, 50))
-        genome, truth, reads = simulate.tile(genome, truth, reads, copies)
-        G *= copies
-        fa = os.path.join(work, "ref.fa")
-        with open(fa, "wb") as f:
-            f.write(b">sim\n" + b"\n".join(genome[i:i + 60] for i in range(0, G, 60)) + b"\n")
-        with open(fa + ".fai", "wb") as f:
-            f.write(b"sim\t%d\t5\t60\t61\n" % G)
-        bam = os.path.join(work, "s.bam")
-        bamio.write_bam(bam, [(b"sim", G)], reads, sample="S")
-        out = os.path.join(work, "calls.vcf")
-        base = ["callVariants", "--bamFiles", bam, "--refFile", fa, "--regions", "sim:1-%d" % (G - 1), "--output", out,
-                "--maxReadLength", "150"]
-        best, cpu = {}, {}
-        for mode in ("device", "host"):                      # where the BGZF blocks are inflated (runner --inflate)
-            for workers in (1, 4, 8):                        # host processes sharing the one GPU
-                extra = ["--inflate", mode]
-                if workers > 1:
-                    extra += ["--workersPerGPU", str(workers), "--processRegionSize", str(G // workers)]
-                for _ in range(2):
-                    # in a process of its own, start-up included, as a user would run it: inside this one the caller
-                    # shares the interpreter with torch and a second HIP runtime, which costs it a sixth of its rate
-                    t0, c0 = time.perf_counter(), os.times()
-                    child = multiprocessing.get_context("spawn").Process(target=runner.main, args=(base + extra,))
-                    child.start()
-                    child.join()
-                    if child.exitcode != 0:
-                        raise RuntimeError("the file-to-file run failed (exit code %s)" % child.exitcode)
-                    dt, c1 = time.perf_counter() - t0, os.times()
-                    if dt < best.get((mode, workers), 1e30):     # host core-seconds of the run: this process, its threads, its children
-                        best[mode, workers] = dt
-                        cpu[mode, workers] = (c1.user - c0.user) + (c1.system - c0.system) + \
-                                             (c1.children_user - c0.children_user) + (c1.children_system - c0.children_system)
-        by_mode = {}
-        for mode in ("device", "host"):
-            d = {"mbp_per_min": G / 1e6 / (best[mode, 1] / 60.0), "seconds": best[mode, 1],
-                 "host_core_seconds_per_mb": cpu[mode, 1] / (G / 1e6)}
-            for workers in (4, 8):
-                d["mbp_per_min_%d_host_processes" % workers] = G / 1e6 / (best[mode, workers] / 60.0)
-                d["seconds_%d_host_processes" % workers] = best[mode, workers]
-                d["host_core_seconds_per_mb_%d_host_processes" % workers] = cpu[mode, workers] / (G / 1e6)
-            by_mode[mode] = d
-        called = set()
-        for line in open(out):
-            if not line.startswith("#"):
-                called.add(int(line.split("\t")[1]) - 1)
-        # top level: what the runner does by itself (--inflate auto): one process inflates the BGZF blocks on the GPU,
-        # several processes that share a GPU leave it to the host library
-        out_d = {k: by_mode["host" if k.endswith("8_host_processes") else "device"][k] for k in by_mode["device"]}
-        out_d["by_inflate_mode"] = by_mode
-        out_d.update({
-                "genome_kb": kb * copies, "simulated_kb": kb, "repeats": copies, "coverage": coverage,
-                "read_length": 150, "paired": True,
-                "reads": int(len(reads["pos"])), "bam_mb": os.path.getsize(bam) / 1e6, "vcf_records": len(called),
-                "planted_variants": len(truth), "planted_found": sum(p in called for p, r, a, g in truth),
-                "processes": 1, "what": "simulated BAM + .bai and FASTA + .fai -> VCF, platypus_amd.runner in a process of its own, "
-                                        "start-up included; BGZF blocks inflated on the GPU with one or four host processes, by the host "
-                                        "library with eight (runner --inflate auto); by_inflate_mode: every combination"})
-        return out_d
-    finally:
-        shutil.rmtree(work, ignore_errors=True)
-
-
-def max_over_ranks(value, dist, device):
-    """MAX all-reduce of one float (the elapsed time): the only cross-rank operation of the run"""
-    import torch
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t.item())
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--windows", type=int, default=32768, help="windows per GPU (128 pairs each)")
-    ap.add_argument("--read-len", type=int, default=150)
-    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--no-e2e", action="store_true", help="skip the file-to-file end-to-end leg")
-    ap.add_argument("--no-stream", action="store_true", help="skip the PCIe-inclusive (streamed batches) leg")
-    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
-                    help="kernel-choice override passed to pg_set_option (measurement sweeps)")
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="wgs",
-                    help="pair stream to synthesise; wgs is the configuration the metric is quoted on")
-    args = ap.parse_args()
-
-    from platypus_amd import shard
-    rank, world, local_rank = shard.rank_info()
-    import torch                                           # (before the caller's library is loaded: torch brings a HIP runtime of its own)
-    # ---- file to file (simulated BAM + FASTA -> VCF through the region caller), not part of the metric:
-    # the second figure BASELINE.json names, Mbp/min, for ONE process / one GPU.  It runs first, while this process
-    # has not opened the GPU: the caller runs in processes of its own, and a parent that holds streams and memory on
-    # the same device takes a tenth off their rate ------------------------------------------------------
-    e2e = None
-    if world == 1 and not args.no_e2e and args.workload == "wgs":
-        try:
-            e2e = end_to_end_leg()
-        except Exception as e:                             # reported, never hidden
-            e2e = {"error": "%s: %s" % (type(e).__name__, e)}
-
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # one rank per GPU; on a box with fewer GPUs than ranks (rehearsals) ranks share devices
-        device = local_rank % max(1, torch.cuda.device_count())
-        torch.cuda.set_device(device)
-        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")   # the process group only carries a barrier and one MAX
-        if backend == "nccl":
-            try:
-                dist.init_process_group("nccl", rank=rank, world_size=world,
-                                        device_id=torch.device("cuda", device))
-                sync_dev = torch.device("cuda", device)
-                dist.barrier()
-            except Exception:                                 # control plane only: gloo will do
-                if dist.is_initialized():
-                    dist.destroy_process_group()
-                backend = "gloo"
-        if backend != "nccl":
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-            sync_dev = torch.device("cpu")
-    else:
-        device = 0
-        torch.cuda.set_device(0)
-
-    from platypus_amd import native, synth
-    L = args.read_len
+# ------------------------------------------------------------------------------------------------------
+# the timed loop of one rank
+def make_batch(args, rank):
+    from platypus_amd import synth
     H, R, extra, text = WORKLOADS[args.workload]
     n_windows = max(1, args.windows * 128 // (H * R))
     batch = synth.make_batch(n_windows=n_windows, haps_per_window=H, reads_per_window=R,
-                             read_len=L, hap_len=750, seed=synth.SEED + rank, **extra)
-    n_pairs = len(batch["pair_hap"])
-    ctx = native.AlignContext(device)
-    for opt in args.option:
-        ctx.set_option(*opt.split("=", 1))
-    ctx.upload_batch(batch)                                    # inputs resident in HBM from here on
+                             read_len=args.read_len, hap_len=750, seed=synth.SEED + rank, **extra)
+    return batch, n_windows
 
-    def barrier():
-        ctx.sync()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
 
+def rank_steps(ctx, args, barrier):
+    """W untimed steps, then exactly K timed steps between two barriers, each with the device drained (pg_sync is a
+    hipStreamSynchronize of the context's stream, the only stream the path uses).  Returns this rank's seconds and
+    the per-step event times of the two kernels."""
+    from platypus_amd import native
     for _ in range(args.warmup):
         ctx.launch()
+    ctx.sync()
     barrier()
     t0 = time.perf_counter()
     k_ms, v_ms = [], []
@@ -244,76 +117,136 @@ def main():
         ctx.sync()
         k_ms.append(ctx.kernel_ms(native.PG_K_ALIGN))
         v_ms.append(ctx.kernel_ms(native.PG_K_ANCHOR))
+    ctx.sync()
     barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        dt = max_over_ranks(dt, dist, sync_dev)
+    return time.perf_counter() - t0, k_ms, v_ms
 
+
+def _child(rank, world, args, barrier, conn):
+    """one rank of a self-launched run: a fresh interpreter that opens its own device and nothing else"""
+    try:
+        from platypus_amd import native
+        ndev = native.device_count()
+        if ndev < 1:
+            raise RuntimeError("no gfx950 device")
+        device = rank % ndev
+        batch, n_windows = make_batch(args, rank)
+        ctx = native.AlignContext(device)
+        for opt in args.option:
+            ctx.set_option(*opt.split("=", 1))
+        ctx.upload_batch(batch)                                # inputs resident in HBM from here on
+        dt, k_ms, v_ms = rank_steps(ctx, args, lambda: barrier.wait(600))
+        n_vote = int((batch["hap_varlen"][batch["pair_hap"]] != 0).sum())
+        conn.send(dict(rank=rank, device=device, devices=ndev, dt=dt, k_ms=k_ms, v_ms=v_ms,
+                       n_pairs=len(batch["pair_hap"]), n_windows=n_windows, n_vote_pairs=n_vote))
+        ctx.close()
+    except BaseException as e:                                 # reported to the parent, never hidden
+        try:
+            barrier.abort()
+        except Exception:
+            pass
+        conn.send(dict(rank=rank, error="%s: %s" % (type(e).__name__, e)))
+    finally:
+        conn.close()
+
+
+def launch_ranks(args, world):
+    """--gpus N without a launcher: N fresh interpreters, one per device; returns their reports in rank order.
+    The parent makes no GPU call."""
+    import multiprocessing
+    mp = multiprocessing.get_context("spawn")
+    barrier = mp.Barrier(world)
+    procs, pipes = [], []
+    for r in range(world):
+        here, there = mp.Pipe(duplex=False)
+        p = mp.Process(target=_child, args=(r, world, args, barrier, there))
+        p.start()
+        there.close()
+        procs.append(p)
+        pipes.append(here)
+    reports = []
+    for r, (p, c) in enumerate(zip(procs, pipes)):
+        try:
+            reports.append(c.recv())
+        except EOFError:
+            reports.append(dict(rank=r, error="rank %d ended without a report" % r))
+    for p in procs:
+        p.join()
+    bad = [rep for rep in reports if "error" in rep] + \
+          [dict(rank=r, error="exit code %s" % p.exitcode) for r, p in enumerate(procs) if p.exitcode != 0]
+    if bad:
+        raise RuntimeError("; ".join("rank %d: %s" % (b["rank"], b["error"]) for b in bad))
+    return reports
+
+
+def slowest(value, dist):
+    """MAX over ranks of one float (the elapsed time): with the barriers, the only cross-rank operation of a run
+    under a launcher.  Host objects through gloo; no device tensor."""
+    gathered = [None] * dist.get_world_size()
+    dist.all_gather_object(gathered, float(value))
+    return max(gathered)
+
+
+# ------------------------------------------------------------------------------------------------------
+def roofline_of(n_pairs, L, k_ms, v_ms, n_vote_pairs, workload, probe=None, pk_peak=None):
+    """Roofline of the dominant kernel (k_align2): share of the VALU issue rate.
+    The kernel is bound by VALU instruction issue (integer DP; no MFMA, 10 % of the HBM rate).
+      achieved = VALU instructions the kernel EXECUTES per launch x 64 lanes / its average duration
+      peak     = 256 CUs x 4 SIMDs x 32 lanes per clock x 2.4 GHz (a wavefront's VALU instruction issues
+                 over 2 cycles), and beside it the rate a probe of the kernel's own instruction forms
+                 (v_add_u16 / v_min_u16) reaches in this process
+    Executed instructions per wavefront are a property of the shipped binary: VALU_A + VALU_B x (L + 8),
+    from SQ_INSTS_VALU / SQ_WAVES of k_align2 at L = 100, 150, 250 (profiles/, see VALU_SOURCE)."""
     cells_per_pair = 16 * (L + 8)
-    total_cells = float(n_pairs) * cells_per_pair * world * args.steps
-    gcups = total_cells / dt / 1e9
-    if rank != 0:
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
-
-    # ---- roofline of the dominant kernel (k_align2): share of the VALU issue rate ------------------
-    # The kernel is bound by VALU instruction issue (integer DP; no MFMA, 10 % of the HBM rate).
-    #   achieved = VALU instructions the kernel EXECUTES per launch x 64 lanes / its average duration
-    #   peak     = 256 CUs x 4 SIMDs x 32 lanes per clock x 2.4 GHz (a wavefront's VALU instruction issues
-    #              over 2 cycles), and beside it the rate a probe of the kernel's own instruction forms
-    #              (v_add_u16 / v_min_u16) reaches in this process
-    # Executed instructions per wavefront are a property of the shipped binary: VALU_A + VALU_B x (L + 8),
-    # from SQ_INSTS_VALU / SQ_WAVES of k_align2 at L = 100, 150, 250 (profiles/, see VALU_SOURCE).
     k_avg = float(np.mean(k_ms)) * 1e-3
-    score, anchor, like = ctx.fetch()
     n_waves = (n_pairs + 63) // 64
     insts_per_wave = VALU_A + VALU_B * (L + 8)
-    lane_instr = float(n_waves) * insts_per_wave * 64.0
-    achieved = lane_instr / k_avg
-    probe = ctx.valu_vop2_rate()
-    pk_peak = ctx.valu_int16_peak()
+    achieved = float(n_waves) * insts_per_wave * 64.0 / k_avg
     algo_ops = float(n_pairs) * cells_per_pair * OPS_PER_CELL       # int16 operations of the reference recurrence
-    traffic, traffic_src = pmc_traffic(n_pairs, L) if args.workload == "wgs" else (None, None)
+    traffic, traffic_src = pmc_traffic(n_pairs, L) if workload == "wgs" else (None, None)
     roofline = {
         "bound": "valu_issue",
         "kernel": "k_align2",
         "achieved": achieved / 1e12, "peak": NOMINAL_LANE_RATE / 1e12, "unit": "T lane-instructions/s",
         "frac": achieved / NOMINAL_LANE_RATE,
         "peak_source": "256 CUs x 4 SIMDs x 32 lanes/clk x 2.4 GHz",
-        "probe_peak": probe / 1e12, "frac_of_probe": achieved / probe,
-        "probe_source": "v_add_u16/v_min_u16 issue-rate probe run in this process",
         "valu_insts_per_wave": insts_per_wave, "valu_insts_source": VALU_SOURCE,
         "kernel_ms": k_avg * 1e3, "anchor_kernel_ms": float(np.mean(v_ms)),
         "kernel_gcups": float(n_pairs) * cells_per_pair / k_avg / 1e9,
-        # the survey's convention, kept for comparison: 14 int16 operations per cell of the reference
-        # recurrence over the packed-int16 probe rate (the kernel needs fewer instructions per cell than
-        # that, so this is not a fraction of anything the hardware limits)
-        "algorithmic_ops_per_s": algo_ops / k_avg / 1e12, "packed_int16_probe": pk_peak / 1e12,
-        "algorithmic_frac": algo_ops / k_avg / pk_peak,
         "hbm_algorithmic_gbps": float(n_pairs) * (2 * L + 24) / k_avg / 1e9,
         "hbm_peak_gbps": 8000.0,
         "hbm_algorithmic_bytes": float(n_pairs) * (2 * L + 24),
         # HBM bytes per launch from the counter passes of a committed profile (not measured in this run)
         "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
     }
-    # the anchoring kernel in front of it (k_vote4) is bound by LDS look-up latency / issue: one table
+    if probe:
+        roofline.update({"probe_peak": probe / 1e12, "frac_of_probe": achieved / probe,
+                         "probe_source": "v_add_u16/v_min_u16 issue-rate probe run in this process"})
+    if pk_peak:
+        # the survey's convention, kept for comparison: 14 int16 operations per cell of the reference
+        # recurrence over the packed-int16 probe rate (the kernel needs fewer instructions per cell than
+        # that, so this is not a fraction of anything the hardware limits)
+        roofline.update({"algorithmic_ops_per_s": algo_ops / k_avg / 1e12, "packed_int16_probe": pk_peak / 1e12,
+                         "algorithmic_frac": algo_ops / k_avg / pk_peak})
+    # the anchoring kernel in front of it is bound by LDS look-up latency / issue: one table
     # look-up per 7-mer of every read of a pair on an indel-bearing haplotype
-    n_vote_pairs = int((batch["hap_varlen"][batch["pair_hap"]] != 0).sum())
     v_avg = float(np.mean(v_ms)) * 1e-3
     lookups = float(n_vote_pairs) * max(0, L - 7)
     roofline_anchor = {
-        "bound": "lds_lookup", "kernel": "k_vote4", "kernel_ms": v_avg * 1e3, "pairs": n_vote_pairs,
+        "bound": "lds_lookup", "kernel": "k_vote", "kernel_ms": v_avg * 1e3, "pairs": n_vote_pairs,
         "achieved": lookups / v_avg / 1e12 if v_avg > 0 else None, "peak": LDS_LOOKUP_PEAK / 1e12,
         "unit": "T look-ups/s", "frac": lookups / v_avg / LDS_LOOKUP_PEAK if v_avg > 0 else None,
         "peak_source": "ds_read_b32 aggregate of the chip, 75 TB/s / 4 B",
     }
+    return roofline, roofline_anchor
 
-    # ---- the consumer of the likelihood matrix (genotype likelihoods + EM per window), not part of
-    # the metric: kernel times of one pass over the same batch; one individual per window, except the
-    # joint-calling stream whose 550 reads per window are 50 individuals' 11 reads each ----------------
-    caller = None
+
+def caller_stage(ctx, args, n_windows):
+    """The consumer of the likelihood matrix (genotype likelihoods + EM per window), not part of the metric: kernel
+    times of one pass over the same batch; one individual per window, except the joint-calling stream whose 550
+    reads per window are 50 individuals' 11 reads each."""
+    from platypus_amd import native
+    H, R, _, _ = WORKLOADS[args.workload]
     n_inds = 50 if args.workload == "joint" else 1
     try:
         ctx.launch()
@@ -334,47 +267,156 @@ def main():
             caller["roofline"] = {"bound": "hbm", "kernel": "k_em_step_sym", "achieved": em_bytes / em_s / 1e9, "peak": 8000.0,
                                   "unit": "GB/s", "frac": em_bytes / em_s / 8e12, "algorithmic_bytes": em_bytes,
                                   "traffic": None}
+        return caller
     except native.PlatGpuError as e:                       # reported, never hidden
-        caller = {"error": str(e)}
+        return {"error": str(e)}
 
-    # ---- PCIe-inclusive rate, never `value`: the same batch streamed from page-locked host memory through the
-    # ABI (everything uploaded and fetched per batch, four contexts fed by a host thread each), beside the link's own rate ----
-    streamed = None
-    if world == 1 and not args.no_stream and args.workload == "wgs":
+
+def cpu_baseline(batch, n_pairs, L, score, anchor):
+    """The reference's own compiled routine (oracle/_ref) on the host cores, over the same arrays; its results are
+    compared with the GPU's."""
+    from oracle import pyoracle as po
+    from platypus_amd import synth
+    cells_per_pair = 16 * (L + 8)
+    cores = min(16, os.cpu_count() or 1)
+    kind = "reference" if po.have_ref() else "port"
+    sample = min(n_pairs, 1 << 22)
+    ov = synth.oracle_view(batch)
+    reps = 3                                              # about 25 s of CPU work in total
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        cs, ca = po.run_pairs(ov, use_ref=(kind == "reference"), threads=cores, hi=sample)
+    cdt = (time.perf_counter() - t1) / reps
+    same = bool(np.array_equal(cs, score[:sample]) and np.array_equal(ca, anchor[:sample]))
+    return {"value": sample * cells_per_pair / cdt / 1e9, "unit": "GCUPS", "cores": cores,
+            "kind": kind, "pairs_per_s": sample / cdt,
+            "sample": "first %d pairs of the GPU batch (same arrays), %d passes of %.2f s wall each, "
+                      "per-pair 7-mer table rebuild as in the reference; DP by %s" %
+                      (sample, reps, cdt, "the reference's compiled align.c" if kind == "reference"
+                       else "the repo's C restatement"),
+            "gpu_equals_cpu_on_sample": same}
+
+
+# ------------------------------------------------------------------------------------------------------
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--windows", type=int, default=32768, help="windows per GPU (128 pairs each)")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the file-to-file end-to-end leg")
+    ap.add_argument("--no-stream", action="store_true", help="skip the PCIe-inclusive (streamed batches) leg")
+    ap.add_argument("--e2e-mb", type=float, default=None, help="length of the simulated reference of the end-to-end leg, Mb")
+    ap.add_argument("--e2e-workers", type=int, default=4, help="host processes per GPU of the multi-process end-to-end runs")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch the ranks, line them up on the barriers and report, without opening a GPU (tests)")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="kernel-choice override passed to pg_set_option (measurement sweeps)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="wgs",
+                    help="pair stream to synthesise; wgs is the configuration the metric is quoted on")
+    args = ap.parse_args()
+
+    from platypus_amd import shard
+    rank, env_world, local_rank = shard.rank_info()
+    launched = env_world > 1                     # started by torch.distributed.run: the ranks are given
+    world = env_world if launched else max(1, args.gpus)
+    if launched and args.gpus not in (1, env_world):
+        sys.stderr.write("bench.py: --gpus %d under a launcher of %d ranks: the launcher's count is used\n" % (args.gpus, env_world))
+    if args.dry_run:
+        return dry_run(args, world, launched, rank)
+
+    dist = None
+    if launched:
+        # control plane only (a barrier and one MAX); gloo on the host, nothing of torch touches the GPU
+        import datetime
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=30))
+
+    # ---- file to file (simulated BAM + FASTA -> VCF through the region caller), not part of the metric:
+    # the second figure BASELINE.json names, Mbp/min.  It runs first, while no process of this run has
+    # opened a GPU: the caller runs in processes of its own, and a parent that holds streams and memory on
+    # the same device takes a tenth off their rate ---------------------------------------------------------
+    e2e = None
+    if rank == 0 and not args.no_e2e:
         try:
-            sys.path.insert(0, os.path.join(ROOT, "tools"))
-            import time_stream
-            streamed = time_stream.measure(W=n_windows, N=48, pinned=True, device=device, batch=batch, threads=4)
-            streamed["link_gbps"] = time_stream.link_rate()
-            streamed["what"] = ("haplotypes, reads and window blocks uploaded, kernels run, score / anchor / likelihood "
-                                "fetched for every batch; bytes_up / link_gbps is the least a batch can take")
+            import bench_e2e
+            e2e = bench_e2e.leg(args.workload, n_gpus=world, workers=args.e2e_workers, mb=args.e2e_mb)
         except Exception as e:                             # reported, never hidden
-            streamed = {"error": "%s: %s" % (type(e).__name__, e)}
+            e2e = {"error": "%s: %s" % (type(e).__name__, e)}
+    if dist is not None:
+        dist.barrier()
 
-    # ---- CPU baseline: the reference's own compiled routine on the host cores ---------
-    cpu = None
-    if world == 1 and not args.no_cpu:                       # rank 0 at N = 1 only: the other ranks would wait
-        from oracle import pyoracle as po
-        cores = min(16, os.cpu_count() or 1)
-        kind = "reference" if po.have_ref() else "port"
-        sample = min(n_pairs, 1 << 22)
-        ov = synth.oracle_view(batch)
-        reps = 3                                              # about 25 s of CPU work in total
-        t1 = time.perf_counter()
-        for _ in range(reps):
-            cs, ca = po.run_pairs(ov, use_ref=(kind == "reference"), threads=cores, hi=sample)
-        cdt = (time.perf_counter() - t1) / reps
-        same = bool(np.array_equal(cs, score[:sample]) and np.array_equal(ca, anchor[:sample]))
-        cpu = {"value": sample * cells_per_pair / cdt / 1e9, "unit": "GCUPS", "cores": cores,
-               "kind": kind, "pairs_per_s": sample / cdt,
-               "sample": "first %d pairs of the GPU batch (same arrays), %d passes of %.2f s wall each, "
-                         "per-pair 7-mer table rebuild as in the reference; DP by %s" %
-                         (sample, reps, cdt, "the reference's compiled align.c" if kind == "reference"
-                          else "the repo's C restatement"),
-               "gpu_equals_cpu_on_sample": same}
+    L = args.read_len
+    H, R, extra, text = WORKLOADS[args.workload]
+    cells_per_pair = 16 * (L + 8)
+    extras = {}
+    if launched or world == 1:
+        from platypus_amd import native
+        ndev = native.device_count()
+        device = local_rank % max(1, ndev)
+        batch, n_windows = make_batch(args, rank)
+        n_pairs = len(batch["pair_hap"])
+        ctx = native.AlignContext(device)
+        for opt in args.option:
+            ctx.set_option(*opt.split("=", 1))
+        ctx.upload_batch(batch)                                    # inputs resident in HBM from here on
+        dt_mine, k_ms, v_ms = rank_steps(ctx, args, (lambda: None) if dist is None else dist.barrier)
+        dts = [dt_mine]
+        if dist is not None:
+            gathered = [None] * world
+            dist.all_gather_object(gathered, dict(rank=rank, device=device, dt=dt_mine, k_ms=float(np.mean(k_ms))))
+            dts = [g["dt"] for g in gathered]
+            if rank != 0:
+                ctx.close()
+                dist.barrier()
+                dist.destroy_process_group()
+                return
+            ranks = [dict(rank=g["rank"], device=g["device"], seconds=g["dt"], kernel_ms=g["k_ms"]) for g in gathered]
+        else:
+            ranks = [dict(rank=0, device=device, seconds=dt_mine, kernel_ms=float(np.mean(k_ms)))]
+        n_vote_pairs = int((batch["hap_varlen"][batch["pair_hap"]] != 0).sum())
+        score, anchor, like = ctx.fetch()
+        probe = ctx.valu_vop2_rate()
+        pk_peak = ctx.valu_int16_peak()
+        roofline, roofline_anchor = roofline_of(n_pairs, L, k_ms, v_ms, n_vote_pairs, args.workload, probe, pk_peak)
+        extras["caller_stage"] = caller_stage(ctx, args, n_windows)
+        # ---- PCIe-inclusive rate, never `value`: the same batch streamed from page-locked host memory through the
+        # ABI (everything uploaded and fetched per batch, four contexts fed by a host thread each), beside the link's own rate
+        streamed = None
+        if world == 1 and not args.no_stream and args.workload == "wgs":
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import time_stream
+                streamed = time_stream.measure(W=n_windows, N=48, pinned=True, device=device, batch=batch, threads=4)
+                streamed["link_gbps"] = time_stream.link_rate()
+                streamed["what"] = ("haplotypes, reads and window blocks uploaded, kernels run, score / anchor / likelihood "
+                                    "fetched for every batch; bytes_up / link_gbps is the least a batch can take")
+            except Exception as e:                             # reported, never hidden
+                streamed = {"error": "%s: %s" % (type(e).__name__, e)}
+        extras["pcie_inclusive"] = streamed
+        extras["pcie_inclusive_gcups"] = streamed.get("gcups") if streamed else None
+        # ---- CPU baseline: rank 0 at N = 1 only (the other ranks would wait) ---------------------------
+        cpu = None
+        if world == 1 and not args.no_cpu:
+            cpu = cpu_baseline(batch, n_pairs, L, score, anchor)
+        ctx.close()
+    else:
+        reports = launch_ranks(args, world)
+        dts = [r["dt"] for r in reports]
+        r0 = reports[0]
+        n_pairs, n_windows = r0["n_pairs"], r0["n_windows"]
+        roofline, roofline_anchor = roofline_of(n_pairs, L, r0["k_ms"], r0["v_ms"], r0["n_vote_pairs"], args.workload)
+        ranks = [dict(rank=r["rank"], device=r["device"], seconds=r["dt"], kernel_ms=float(np.mean(r["k_ms"]))) for r in reports]
+        extras["devices_visible"] = r0["devices"]
+        cpu = None
 
+    dt = max(dts)                                                  # the slowest rank's time
+    total_cells = float(n_pairs) * cells_per_pair * world * args.steps
     out = {
-        "metric": "read_x_haplotype_align_gcups", "value": gcups, "unit": "GCUPS",
+        "metric": "read_x_haplotype_align_gcups", "value": total_cells / dt / 1e9, "unit": "GCUPS",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "int16", "data": "synthetic",
@@ -382,21 +424,58 @@ def main():
                                "; whole hot path (anchoring + banded DP + likelihood)",
                    "workload_name": args.workload,
                    "pairs_per_gpu": n_pairs, "read_len": L, "cells_per_pair": cells_per_pair,
-                   "parallelism": "region shards, %d process(es), no collective" % world},
+                   "parallelism": "region shards, %d process(es) (%s), one per GPU, no collective" % (
+                       world, "given by the launcher" if launched else "started by this command")},
         "pairs_per_s": float(n_pairs) * world * args.steps / dt,
+        "ranks": ranks,
         "roofline": roofline,
         "roofline_anchor": roofline_anchor,
         "cpu_baseline": cpu,
-        "caller_stage": caller,
-        "pcie_inclusive": streamed,
-        "pcie_inclusive_gcups": streamed.get("gcups") if streamed else None,
-        "end_to_end": e2e,
     }
+    if cpu is None:
+        out["cpu_baseline_why"] = ("measured on rank 0 at N = 1 only" if world > 1 else "skipped with --no-cpu")
+    out.update(extras)
+    out["end_to_end"] = e2e
     print(json.dumps(out), flush=True)
-    ctx.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------------
+def _dry_child(rank, world, barrier, conn):
+    barrier.wait(60)
+    t0 = time.perf_counter()
+    time.sleep(0.05 * (rank + 1))                             # a stand-in for the K steps: rank r takes 50 (r + 1) ms
+    barrier.wait(60)
+    conn.send(dict(rank=rank, dt=time.perf_counter() - t0, pid=os.getpid()))
+    conn.close()
+
+
+def dry_run(args, world, launched, rank):
+    """The launcher without a GPU: starts the ranks the way the real run does, lines them up on the same barriers
+    and prints one line with n_gpus = the ranks that ran (what the CPU tests call)."""
+    if launched:
+        raise SystemExit("--dry-run is for the self-launched mode")
+    import multiprocessing
+    mp = multiprocessing.get_context("spawn")
+    barrier = mp.Barrier(world)
+    procs, pipes = [], []
+    for r in range(world):
+        here, there = mp.Pipe(duplex=False)
+        p = mp.Process(target=_dry_child, args=(r, world, barrier, there))
+        p.start()
+        there.close()
+        procs.append(p)
+        pipes.append(here)
+    reports = [c.recv() for c in pipes]
+    for p in procs:
+        p.join()
+    assert all(p.exitcode == 0 for p in procs)
+    dt = max(r["dt"] for r in reports)
+    print(json.dumps({"metric": "read_x_haplotype_align_gcups", "dry_run": True, "n_gpus": len(reports),
+                      "seconds": dt, "ranks": [dict(rank=r["rank"], seconds=r["dt"], pid=r["pid"]) for r in reports],
+                      "parent_pid": os.getpid()}), flush=True)
 
 
 if __name__ == "__main__":

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 4
+#define PG_ABI_VERSION 5
 
 enum {
     PG_OK = 0,
@@ -48,6 +48,14 @@ typedef struct pg_ctx pg_ctx;
 
 /* ABI version of the loaded library (compare with PG_ABI_VERSION). */
 int pg_abi_version(void);
+
+/*
+ * Number of gfx950 devices this process can open (0 when there is none).  A
+ * launcher that starts one worker per GPU binds worker k to device
+ * k mod this number.  Replaces: nothing in the reference; its counterpart is
+ * the --nCPU option that sizes the worker pool (platypus/runner.py:98,132).
+ */
+int pg_device_count(int *count);
 
 /*
  * One context per process and GPU.  `max_read_len` bounds the read length the

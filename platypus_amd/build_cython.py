@@ -11,7 +11,7 @@ import sysconfig
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-MODULES = ["cbam", "variant", "calign", "cwindow", "chaplotype", "cgenotype", "cpopulation"]
+MODULES = ["cbam", "csimulate", "variant", "calign", "cwindow", "chaplotype", "cgenotype", "cpopulation"]
 # plain Python modules of the region caller, compiled as they are (same source, same semantics, less interpreter
 # time per window); the .py files stay the source, and are what runs where the build has not been done
 PY_MODULES = ["pipeline", "vcfout"]

@@ -372,6 +372,18 @@ const char* pg_last_error_string(const pg_ctx* ctx) {
     return ctx ? ctx->err.c_str() : g_create_error.c_str();
 }
 
+int pg_device_count(int* count) {
+    if (!count) return PG_ERR_INVALID;
+    *count = 0;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) return PG_OK;        // no driver, no device: zero
+    for (int d = 0; d < ndev; ++d) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d) == hipSuccess && std::strncmp(prop.gcnArchName, "gfx950", 6) == 0) ++*count;
+    }
+    return PG_OK;
+}
+
 int pg_ctx_create(int device_ordinal, int max_read_len, pg_ctx** out) {
     if (!out) return fail(nullptr, PG_ERR_INVALID, "pg_ctx_create: out is NULL");
     *out = nullptr;

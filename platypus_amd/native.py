@@ -17,13 +17,14 @@ PG_OK = 0
 PG_ERR_NO_DEVICE, PG_ERR_INVALID, PG_ERR_HIP, PG_ERR_UNSUPPORTED, PG_ERR_STATE = -1, -2, -3, -4, -5
 PG_SCORE_ASSERT_FAILED = -1
 PG_K_ANCHOR, PG_K_ALIGN, PG_K_GENOTYPE, PG_K_CALLER_SETUP, PG_K_CALLER_EM = 0, 1, 2, 3, 4
-ABI_VERSION = 4
+ABI_VERSION = 5
 NOALLOC_MAX_PAIRS, NOALLOC_MAX_INDEL_HAPS = 262144, 65536      # PG_NOALLOC_MAX_* of include/platgpu.h
 
 # every symbol include/platgpu.h declares: (restype, argtypes)
 _i32p, _i64p, _f64p = C.c_void_p, C.c_void_p, C.c_void_p
 SYMBOLS = {
     "pg_abi_version": (C.c_int, []),
+    "pg_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "pg_ctx_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "pg_ctx_destroy": (C.c_int, [C.c_void_p]),
     "pg_last_error_string": (C.c_char_p, [C.c_void_p]),
@@ -110,6 +111,13 @@ def pinned_array(shape, dtype):
 
 
 _PINNED = {}
+
+
+def device_count():
+    """gfx950 devices this process can open (initialises the HIP runtime)"""
+    n = C.c_int(0)
+    LIB.pg_device_count(C.byref(n))
+    return n.value
 
 
 class AlignContext(object):

@@ -66,6 +66,7 @@ def call_chunks(chunks, args, tmpdir):
     units = [(ch, s, min(s + args.bufferSize, ch[2])) for ch in chunks for s in range(ch[1], ch[2], args.bufferSize)]
 
     spent = {"fetch": 0.0, "buffers": 0.0, "candidates": 0.0, "wait": 0.0, "call": 0.0, "write": 0.0}
+    counts = {"windows": 0, "called_windows": 0, "candidates": 0}
     phases = {}                                           # seconds per phase of callRegion, summed (timing report only)
     timed = bool(os.environ.get("PLATYPUS_AMD_TIMINGS"))
 
@@ -178,6 +179,8 @@ def call_chunks(chunks, args, tmpdir):
                 for k, v in stats.items():
                     if k.startswith("t_") or k in ("pack", "upload", "device", "unpack"):
                         phases[k] = phases.get(k, 0.0) + v
+                    elif k in counts:
+                        counts[k] += v
             t1 = time.perf_counter()
             for c in calls:
                 out.write(vcfout.record(c, fa) + "\n")
@@ -189,9 +192,9 @@ def call_chunks(chunks, args, tmpdir):
     for r in readers + opened:
         r.close()
     if timed:                                             # where a worker's time went (helper thread: fetch, buffers)
-        sys.stderr.write("worker %d: %d calls; helper threads: fetch %.2f s, buffers %.2f s, candidates %.2f s; main thread: "
+        sys.stderr.write("worker %d: %d calls from %d candidates in %d windows (%d with reads and more than one haplotype); helper threads: fetch %.2f s, buffers %.2f s, candidates %.2f s; main thread: "
                          "waiting %.2f s, calling %.2f s, writing %.2f s; phases of calling: %s\n" % (
-                             os.getpid(), n_calls, spent["fetch"], spent["buffers"], spent["candidates"], spent["wait"],
+                             os.getpid(), n_calls, counts["candidates"], counts["windows"], counts["called_windows"], spent["fetch"], spent["buffers"], spent["candidates"], spent["wait"],
                              spent["call"], spent["write"],
                              ", ".join("%s %.2f" % (k, v) for k, v in sorted(phases.items()))))
     return n_calls
@@ -222,7 +225,10 @@ def _single_threaded():
 
 
 def _worker(rank, chunks, args, tmpdir, queue, forked=False):
-    os.environ["PLATGPU_DEVICE"] = str(rank % max(1, args.nGPU))     # workers of one GPU share its device
+    # workers of one GPU share its device; on a machine with fewer devices than --nGPU names (a rehearsal of a larger
+    # run) the GPUs asked for are dealt onto the ones there are
+    from platypus_amd import native
+    os.environ["PLATGPU_DEVICE"] = str((rank % max(1, args.nGPU)) % max(1, native.device_count()))
     queue.put((rank, call_chunks(chunks, args, tmpdir)))
     if forked:
         # multiprocessing ends a forked child without the C library's exit handlers, so the HIP runtime would never shut
@@ -271,7 +277,7 @@ def main(argv=None):
     ap.add_argument("--getVariantsFromBAMs", type=int, default=1)
     for unsupported in ("--source", "--useCortex", "--freqAsPrior"):
         ap.add_argument(unsupported, default=None, help="not supported by this build")
-    ap.add_argument("--processRegionSize", type=int, default=1000000)
+    ap.add_argument("--processRegionSize", type=int, default=30000000)       # the reference's default (platypus/runner.py:181)
     ap.add_argument("--bufferSize", type=int, default=1000000)
     from platypus_amd import pipeline
     for k, v in vars(pipeline.Options()).items():

@@ -194,3 +194,167 @@ def tile(genome, variants, reads, copies):
         out[k] = np.concatenate([reads[k][:-1] + c * step for c in range(copies)] + [np.array([copies * step])]).astype(np.int64)
     truth = [(p + c * G, rem, add, gt) for c in range(copies) for p, rem, add, gt in variants]
     return genome * copies, truth, out
+
+
+# ---------------------------------------------------------------------------------------------
+# Whole-chromosome simulation (end-to-end timing runs): the loops over reads are compiled
+# (platypus_amd/csimulate.pyx), everything else is array arithmetic.
+def chr_like_genome(rng, length, gc=0.44, homopolymer_every=4000, repeat_every=15000):
+    """A chromosome-like sequence: GC content `gc`, a homopolymer run of 8-20 bases every
+    `homopolymer_every` bases on average and a di- or trinucleotide repeat of 6-15 units every
+    `repeat_every` (the low-complexity sequence real chromosomes hold and a uniform draw lacks)."""
+    p = np.array([(1 - gc) / 2, gc / 2, gc / 2, (1 - gc) / 2])
+    g = ACGT[rng.choice(4, size=length, p=p)]
+    n_h = max(0, length // homopolymer_every)
+    at = rng.integers(300, max(301, length - 300), n_h)
+    ln = rng.integers(8, 21, n_h)
+    base = ACGT[rng.integers(0, 4, n_h)]
+    for a, l, b in zip(at.tolist(), ln.tolist(), base.tolist()):
+        g[a:a + l] = b
+    n_r = max(0, length // repeat_every)
+    at = rng.integers(300, max(301, length - 300), n_r)
+    for a in at.tolist():
+        unit = ACGT[rng.integers(0, 4, int(rng.integers(2, 4)))]
+        if len(set(unit.tolist())) == 1:
+            continue
+        rep = np.tile(unit, int(rng.integers(6, 16)))
+        g[a:a + len(rep)] = rep[:max(0, min(len(rep), length - 300 - a))] if a + len(rep) > length - 300 else rep
+    return g.tobytes()
+
+
+def left_align(genome, pos, rem, add):
+    """the left-most equivalent of an insertion after / deletion behind `pos` (SNPs are returned as they are)"""
+    if len(rem) == len(add):
+        return pos, rem, add
+    if add:
+        while pos > 0 and add[-1:] == genome[pos:pos + 1]:
+            add = genome[pos:pos + 1] + add[:-1]
+            pos -= 1
+        return pos, rem, add
+    while pos > 0 and rem[-1:] == genome[pos:pos + 1]:
+        rem = genome[pos:pos + 1] + rem[:-1]
+        pos -= 1
+    return pos, rem, add
+
+
+def plant_variants_rate(rng, genome, rate=0.001, indel_frac=0.15, indel_extend=0.3, margin=300, het_frac=0.6667):
+    """Variants at exponential gaps of mean 1 / rate (wgsim's parameters: mutation rate 0.001, 15 % indels whose
+    length grows with probability 0.3 per base), each (pos, removed, added, genotype) in the package's
+    conventions and in left-aligned form; an indel is kept at least its own length + 12 bases from the previous variant."""
+    out, pos, last_end = [], margin, 0
+    n = len(genome)
+    while True:
+        pos += 1 + int(rng.geometric(rate))
+        if pos >= n - margin:
+            break
+        gt = 1 if rng.random() < het_frac else 2
+        if rng.random() < indel_frac:
+            k = 1
+            while k < 30 and rng.random() < indel_extend:
+                k += 1
+            if rng.random() < 0.5:
+                p, rem, add = left_align(genome, pos, b"", ACGT[rng.integers(0, 4, k)].tobytes())
+            else:
+                p, rem, add = left_align(genome, pos, genome[pos + 1:pos + 1 + k], b"")
+            if p <= last_end + 12:
+                continue
+            out.append((p, rem, add, gt))
+            last_end = max(pos, p) + k + 1
+            pos = last_end
+        else:
+            if pos <= last_end + 1:
+                continue
+            ref = genome[pos:pos + 1]
+            alt = [b for b in b"ACGT" if b != ref[0]][int(rng.integers(0, 3))]
+            out.append((pos, ref, bytes([alt]), gt))
+            last_end = pos
+    return out
+
+
+def _runs(seq, min_run=6):
+    """(start, length) of the runs of at least min_run equal bases of a sequence"""
+    a = np.frombuffer(seq, dtype=np.uint8)
+    change = np.flatnonzero(a[1:] != a[:-1]) + 1
+    starts = np.concatenate([[0], change])
+    lens = np.diff(np.concatenate([starts, [len(a)]]))
+    keep = lens >= min_run
+    return starts[keep].astype(np.int64), lens[keep].astype(np.int32)
+
+
+def simulate_pairs(seed, genome, variants, coverage=30, read_len=150, insert=(500, 50), chrom=b"sim",
+                   fragments=None, run_err_scale=2e-5, threads=None):
+    """Read pairs of a diploid sample (packed record arrays, sorted by position) with qualities that mean what they
+    say, errors where the qualities are low and indel errors in homopolymer runs (csimulate.fill / place).
+    `fragments`: (reference start, length) arrays to draw the fragments from instead of uniform positions (panels)."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    from platypus_amd import csimulate
+    rng = np.random.default_rng(seed)
+    L = read_len
+    copies = [_copy(genome, variants, w) for w in (0, 1)]
+    if fragments is None:
+        n_frag = int(coverage * len(genome) / (2 * L))
+        flen = np.maximum(L, np.rint(rng.normal(insert[0], insert[1], n_frag))).astype(np.int32)
+        fstart = None
+    else:
+        fstart, flen = np.asarray(fragments[0], dtype=np.int64), np.asarray(fragments[1], dtype=np.int32)
+        n_frag = len(fstart)
+    which = rng.integers(0, 2, n_frag).astype(np.uint8)
+    first_is_left = rng.random(n_frag) < 0.5
+    frag_id = np.arange(n_frag, dtype=np.int64)
+    parts = []
+    haps = []
+    for c in (0, 1):
+        seq, segs = copies[c]
+        haps.append(np.frombuffer(seq, dtype=np.uint8))
+        seg_ref = np.array([s[0] for s in segs], dtype=np.int64)
+        seg_hap = np.array([s[1] for s in segs], dtype=np.int64)
+        seg_len = np.array([s[2] for s in segs], dtype=np.int64)
+        seg_op = np.array([{"M": 0, "I": 1, "D": 2}[s[3]] for s in segs], dtype=np.uint8)
+        mine = np.flatnonzero(which == c)
+        if fstart is None:
+            fs = (rng.random(len(mine)) * (len(seq) - flen[mine] - 4)).astype(np.int64)
+        else:                                              # reference position -> position in this copy
+            m = seg_op == 0
+            mref, mhap = seg_ref[m], seg_hap[m]
+            at = np.maximum(0, np.searchsorted(mref, fstart[mine], side="right") - 1)
+            fs = np.clip(mhap[at] + (fstart[mine] - mref[at]), 0, len(seq) - flen[mine] - 4)
+        rs, rl = _runs(seq)
+        got = csimulate.place(seed, c, seg_ref, seg_hap, seg_len, seg_op, rs, rl, fs,
+                              np.ascontiguousarray(flen[mine]), np.ascontiguousarray(frag_id[mine]), L, run_err_scale)
+        got["frag"] = np.repeat(mine, 2)
+        got["which"] = np.full(2 * len(mine), c, dtype=np.uint8)
+        parts.append(got)
+    cat = {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+    n = len(cat["pos"])
+    ok = cat["pos"] >= 0
+    ok = ok & np.repeat(ok[0::2] & ok[1::2], 2)             # both reads of a pair or neither
+    side = np.tile(np.array([0, 1], dtype=np.uint8), n // 2)
+    mate = np.arange(n) ^ 1
+    mate_pos = cat["pos"][mate]
+    tlen = np.repeat(cat["end"][1::2] - cat["pos"][0::2], 2)
+    tlen = np.where(side == 0, tlen, -tlen)
+    fil = first_is_left[cat["frag"]]
+    flag = np.where(side == 0, 0x1 | 0x2 | 0x20 | np.where(fil, 0x40, 0x80), 0x1 | 0x2 | 0x10 | np.where(fil, 0x80, 0x40))
+    keep = np.flatnonzero(ok)
+    order = keep[np.argsort(cat["pos"][keep], kind="stable")]
+    m = len(order)
+    seq = np.empty(m * L, dtype=np.uint8)
+    qual = np.empty(m * L, dtype=np.uint8)
+    hs = np.ascontiguousarray(cat["hs"][order]); hlen = np.ascontiguousarray(cat["hlen"][order])
+    ek = np.ascontiguousarray(cat["ekind"][order]); eo = np.ascontiguousarray(cat["eoff"][order])
+    wh = np.ascontiguousarray(cat["which"][order]); rev = np.ascontiguousarray(side[order])
+    rid = np.ascontiguousarray((2 * cat["frag"] + side)[order].astype(np.int64))
+    threads = threads or min(16, os.cpu_count() or 1)
+    cuts = [m * t // threads for t in range(threads + 1)]
+    with ThreadPoolExecutor(threads) as pool:
+        list(pool.map(lambda t: csimulate.fill(seed, haps[0], haps[1], wh, hs, hlen, ek, eo, rev, rid, L, seq, qual,
+                                               cuts[t], cuts[t + 1]), range(threads)))
+    nc = cat["ncig"][order]
+    cig = cat["cigar"][order]
+    cigar = cig[np.arange(cig.shape[1])[None, :] < nc[:, None]]
+    return dict(chrom=chrom, seq=seq, qual=qual, off=np.arange(m + 1, dtype=np.int64) * L,
+                pos=cat["pos"][order].astype(np.int32), mapq=np.full(m, 60, dtype=np.int32),
+                flag=flag[order].astype(np.int32), cigar=cigar.astype(np.uint32),
+                cigarOff=np.concatenate([[0], np.cumsum(nc, dtype=np.int64)]),
+                matePos=mate_pos[order].astype(np.int32), insertSize=tlen[order].astype(np.int32))

@@ -51,7 +51,7 @@ mine = shard.assign(chunks, world)[rank]
 # a stand-in for "call variants in my chunks": one body line per chunk
 parts = {shard.region_name(c): ["#header", "%%s\t%%d" %% (c[0], c[1])] for c in mine}
 dist.barrier()
-t = bench.max_over_ranks(0.25 * (rank + 1), dist, "cpu")
+t = bench.slowest(0.25 * (rank + 1), dist)
 gathered = [None] * world
 dist.all_gather_object(gathered, parts)      # host-side merge of per-shard outputs, not a data-path collective
 if rank == 0:
@@ -91,3 +91,22 @@ def test_two_ranks_gloo(tmp_path):
     chunks = shard.split_regions([("chr20", None, 3_000_000), ("chr3", None, 900_000)], 500_000)
     single = shard.merge_outputs({shard.region_name(c): ["#header", "%s\t%d" % (c[0], c[1])] for c in chunks})
     assert res["n"] == len(chunks) and res["merged"] == single   # same file as one process would write
+
+
+def test_bench_launches_its_own_ranks():
+    """`bench.py --gpus 2` without a launcher starts two fresh interpreters itself (the parent opens no GPU), lines
+    them up on the run's barriers and prints ONE line with n_gpus = 2 and the slowest rank's time; --dry-run replaces
+    the device work by a sleep of 50 ms x (rank + 1)"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    done = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=env, cwd=ROOT,
+                          capture_output=True, text=True, timeout=120)
+    assert done.returncode == 0, done.stderr[-2000:]
+    lines = [l for l in done.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and [r["rank"] for r in res["ranks"]] == [0, 1]
+    pids = {r["pid"] for r in res["ranks"]}
+    assert len(pids) == 2 and res["parent_pid"] not in pids            # ranks are processes of their own
+    assert res["seconds"] == max(r["seconds"] for r in res["ranks"]) and 0.09 < res["seconds"] < 5.0
+    assert res["ranks"][1]["seconds"] > res["ranks"][0]["seconds"] - 0.02  # both left the first barrier together
