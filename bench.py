@@ -379,9 +379,12 @@ def main():
             ranks = [dict(rank=0, device=device, seconds=dt_mine, kernel_ms=float(np.mean(k_ms)))]
         n_vote_pairs = int((batch["hap_varlen"][batch["pair_hap"]] != 0).sum())
         score, anchor, like = ctx.fetch()
+        n_anchored, n_named, n_full = ctx.anchor_stats()
         probe = ctx.valu_vop2_rate()
         pk_peak = ctx.valu_int16_peak()
         roofline, roofline_anchor = roofline_of(n_pairs, L, k_ms, v_ms, n_vote_pairs, args.workload, probe, pk_peak)
+        roofline_anchor["pairs_counted_over_named_positions"] = n_named
+        roofline_anchor["pairs_counted_over_every_position"] = n_full
         extras["caller_stage"] = caller_stage(ctx, args, n_windows)
         # ---- PCIe-inclusive rate, never `value`: the same batch streamed from page-locked host memory through the
         # ABI (everything uploaded and fetched per batch, four contexts fed by a host thread each), beside the link's own rate

@@ -102,6 +102,10 @@ int pg_set_params(pg_ctx *ctx, int gapextend, int nucprior, const char *table, i
  *   "em_step"        full | sym            the "multi" path's step reads whole matrices or their upper triangle
  *   "em_step_waves"  1..16 wavefronts per workgroup of the triangle step
  *   "vote_waves"     1..4 wavefronts per workgroup of the anchoring kernel
+ *   "vote_grid"      workgroups of the bit-parallel anchoring kernel (each loops over haplotypes)
+ *   "vote_kernel"    table | bits          anchoring by a 16384-entry position table per haplotype in LDS, or by exact
+ *                                          bit-parallel counts for candidate positions (the default for reads of up to
+ *                                          263 bases; longer reads always take the table)
  *   "align_lds_pad"  bytes of unused LDS per workgroup of the DP kernel (lowers occupancy)
  * The process environment is never consulted.
  */
@@ -244,6 +248,17 @@ int pg_map_read(pg_ctx *ctx, const char *read, int read_len, int seq_len, const 
  * context's stream.  Synchronises.
  */
 int pg_kernel_time_ms(pg_ctx *ctx, int which, float *ms);
+
+/*
+ * Counts of the last pg_align_launch's anchoring step (synchronises):
+ * counts[0] pairs on indel-bearing haplotypes (the ones platypus/calign.pyx:66-77
+ * maps by 7-mer votes); counts[1] how many of them the bit-parallel kernel's
+ * candidate positions did not decide, so that a wavefront counted the positions
+ * their 7-mers name; counts[2] how many it counted over every position (both 0
+ * when the position-table kernel ran).  Measurement only; no counterpart in the
+ * reference.
+ */
+int pg_anchor_stats(pg_ctx *ctx, int64_t counts[3]);
 
 /*
  * Genotype log-likelihoods from the likelihoods of the last launch, which

@@ -529,6 +529,423 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 }
 
 // ---------------------------------------------------------------------------
+// k_hap_unique (upload pass, once per haplotype): which starts of an indel-bearing
+// haplotype own a 7-mer that occurs exactly once among the starts the reference
+// hashes (0 .. len - 8, platypus/calign.pyx:114-121) -- the entries of the
+// reference's table that are > 0.  Written as a row beside the haplotype's 2-bit
+// packed bases, in the same layout: bit 2 (p % 16) of word p / 16.
+// One workgroup per haplotype; the 16384-entry table of the reference in LDS.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_hap_unique(const uint32_t* __restrict__ hap2, const VoteHap* __restrict__ vh,
+                                                    uint32_t* __restrict__ hapU)
+{
+    __shared__ uint16_t tab[kHashSize];
+    const int tid = threadIdx.x;
+    const VoteHap H = vh[blockIdx.x];
+    const uint32_t* hw = hap2 + H.hap2off;
+    const int nk = H.len - kHashNucs;
+    {
+        uint4* z = reinterpret_cast<uint4*>(tab);
+        for (int i = tid; i < kHashSize / 8; i += 256) z[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+    }
+    __syncthreads();
+    for (int i = tid; i < nk; i += 256) tab[hash7_packed(hw, i)] = (uint16_t)(i + 1);
+    __syncthreads();
+    for (int i = tid; i < nk; i += 256) {               // some other start owns the slot: the 7-mer is repeated
+        const uint32_t k = hash7_packed(hw, i);
+        if (tab[k] != (uint16_t)(i + 1)) tab[k] = 0xffffu;
+    }
+    __syncthreads();
+    const int nw = (H.len + 15) / 16 + 2;
+    for (int w = tid; w < nw; w += 256) {
+        uint32_t bits = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int i = 16 * w + k;
+            if (i < nk && tab[hash7_packed(hw, i)] == (uint16_t)(i + 1)) bits |= 1u << (2 * k);
+        }
+        hapU[H.hap2off + w] = bits;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_vote5: the anchoring of platypus/calign.pyx:99-158 without the position table.
+//
+// A vote of read offset i for haplotype position c exists exactly when the read's
+// 7-mer at i equals the haplotype's 7-mer at c + i and that start owns a unique
+// 7-mer (k_hap_unique).  For a GIVEN c the votes of sixteen read offsets are
+// therefore one line of bit arithmetic on the 2-bit packed rows: xor of the read's
+// words with the haplotype's words shifted to c, "equal" bits, runs of seven
+// (three and-with-shift steps), and with the uniqueness row at the same shift,
+// popcount.  Exact counts n_k for a few candidate positions decide a read as the
+// reference does whenever the best of them beats every vote that is not theirs:
+//   top = max n_k  >  rest = (voting 7-mers of the read) - sum n_k  >=  any other count
+// (ties between candidates: the one whose last vote comes first reached the final
+// maximum first, platypus/calign.pyx:150-153).  Candidates only have to be GOOD,
+// not exact: they come from a small direct-mapped table of the haplotype's 7-mer
+// starts (4096 x u16, last writer wins, never cleared; every hit is verified
+// against the haplotype's rows).  Four lanes per read, four steps, each taken only
+// by the wavefronts that still hold an undecided read:
+//   1  candidates from the read's first and last eight 7-mers; rest bounded by the
+//      number of the read's 7-mers that do not equal the haplotype's at any
+//      candidate's place (one that does votes there or, repeated, nowhere)
+//   2  rest from the number of 7-mers that vote at all (one bit per 7-mer value:
+//      owned by a unique start), and a third candidate from the read's middle
+//   3  the wavefront takes the read: every lane counts the positions its own
+//      offsets name; a position nobody could name (its table slot was taken by
+//      another 7-mer) holds at most `lost` votes, so the best count decides when
+//      it is above that
+//   4  the count for EVERY position: largest count, earliest last vote
+// LDS per workgroup: the haplotype's code and uniqueness words, zero-padded by a
+// read length on both sides (no shift needs a bounds test), the candidate table
+// (8 KiB), the bit set (2 KiB) and one packed read per wavefront.
+// Reads of up to 263 bases (sixteen 16-base groups, in registers); the host
+// sends launches with longer reads to k_vote4.
+// ---------------------------------------------------------------------------
+constexpr int kCandSlots = 4096;
+constexpr int kNoCand = 0x40000000;
+
+__device__ __forceinline__ uint32_t cand_slot(uint32_t key) { return (key ^ (key >> 7)) & (uint32_t)(kCandSlots - 1); }
+
+// votes of read offsets 16 g .. 16 g + 15 (read words rl, rh = offsets 16 g .. 16 g + 31) for the position whose
+// offset-16g base sits at padded row index s; result: bit 2 k set = offset 16 g + k votes (vm: offsets that exist).
+// An offset whose 7-mer merely EQUALS the haplotype's there (`matches`) votes for no other position either: a
+// unique 7-mer votes for this one, a repeated one for none.
+template <bool MATCHES = false>
+__device__ __forceinline__ uint32_t vote_bits(const uint2* __restrict__ hu, uint32_t rl, uint32_t rh, int s, uint32_t vm,
+                                              uint32_t* matches = nullptr)
+{
+    const int wi = s >> 4;
+    const uint32_t sh = 2u * ((uint32_t)s & 15u);
+    const uint2 a = hu[wi], b = hu[wi + 1], c = hu[wi + 2];
+    const uint32_t hl = __builtin_amdgcn_alignbit(b.x, a.x, sh), hh = __builtin_amdgcn_alignbit(c.x, b.x, sh);
+    const uint32_t u = __builtin_amdgcn_alignbit(b.y, a.y, sh);
+    const uint32_t xl = rl ^ hl, xh = rh ^ hh;
+    const uint32_t el = ~(xl | (xl >> 1)), eh = ~(xh | (xh >> 1));           // even bits: bases equal
+    const uint32_t a1l = el & __builtin_amdgcn_alignbit(eh, el, 2), a1h = eh & (eh >> 2);          // runs of 2
+    const uint32_t a2l = a1l & __builtin_amdgcn_alignbit(a1h, a1l, 4), a2h = a1h & (a1h >> 4);    // runs of 4
+    const uint32_t m7 = a2l & __builtin_amdgcn_alignbit(a2h, a2l, 6) & vm;                         // runs of 7
+    if (MATCHES) *matches = m7;                 // the read's 7-mer is the haplotype's at that place, unique or not
+    return m7 & u;
+}
+
+__device__ __forceinline__ uint32_t group_mask(int nv, int g) {           // offsets 16 g + k < nv
+    const int left = nv - 16 * g;
+    return left >= 16 ? 0x55555555u : (left <= 0 ? 0u : (0x55555555u & ((1u << (2 * left)) - 1u)));
+}
+
+// start of the haplotype's 7-mer `key` according to the candidate table; true if the haplotype really holds the
+// 7-mer there and that start owns it alone
+__device__ __forceinline__ bool cand_lookup(const uint2* __restrict__ hu, const uint16_t* __restrict__ ctab, int pad, int nk,
+                                            uint32_t key, int& j)
+{
+    j = (int)ctab[cand_slot(key)];
+    const int jj = j < nk ? j : 0;                                            // (a slot nobody wrote holds anything)
+    const uint2 a = hu[pad + (jj >> 4)], b = hu[pad + (jj >> 4) + 1];
+    const uint32_t sh = 2u * ((uint32_t)jj & 15u);
+    const uint32_t hk = __builtin_amdgcn_alignbit(b.x, a.x, sh) & 0x3fffu;
+    return j < nk && hk == key && ((a.y >> sh) & 1u);
+}
+
+// window of eight 7-mers a lane of a read's quad looks at for the first two candidates: lanes 0 and 2 the read's
+// first eight (four each), lanes 1 and 3 its last eight
+__device__ __forceinline__ int vote5_window(int part, int nv) { return (part & 1) && nv > 8 ? nv - 8 : 0; }
+
+struct VoteWords5 {
+    uint2 g[4];        // word pairs of the lane's groups part, part + 4, part + 8, part + 12
+    uint32_t c[3];     // the words of its candidate window
+    uint32_t m[3];     // the words of the middle window (sixteen 7-mers from offset nv / 2 on)
+};
+
+__device__ __forceinline__ void vote5_fetch(VoteWords5& Q, const uint32_t* __restrict__ rw, int part, int nv, int n_groups)
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        Q.g[j] = make_uint2(0, 0);
+        if (part + 4 * j < n_groups) __builtin_memcpy(&Q.g[j], rw + part + 4 * j, 8);
+    }
+    Q.c[0] = Q.c[1] = Q.c[2] = Q.m[0] = Q.m[1] = Q.m[2] = 0;
+    if (nv > 0) {
+        __builtin_memcpy(Q.c, rw + (vote5_window(part, nv) >> 4), 12);
+        __builtin_memcpy(Q.m, rw + ((nv >> 1) >> 4), 12);
+    }
+}
+
+// the 7-mer at read offset i from the three words that start at word w0
+__device__ __forceinline__ uint32_t key_from3(const uint32_t* c, int i, int w0) {
+    const int bit = 2 * (i - 16 * w0);                                        // 0 .. 62
+    const uint32_t lo = bit < 32 ? c[0] : c[1], hi = bit < 32 ? c[1] : c[2];
+    return __builtin_amdgcn_alignbit(hi, lo, bit & 31) & 0x3fffu;
+}
+
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_vote5(const uint32_t* __restrict__ hap2, const uint32_t* __restrict__ hapU,
+                                               const uint32_t* __restrict__ read2, const VoteHap* __restrict__ vh,
+                                               const int32_t* __restrict__ rec_start, const VoteRec* __restrict__ vh_recs,
+                                               int32_t* __restrict__ status, int32_t* __restrict__ anchor,
+                                               int pad, int row_cap, int n_vote_haps)
+{
+    if (status[0] != 0x7fffffff) return;             // nothing runs on a list with an index out of range
+    extern __shared__ uint32_t lds[];
+    uint2* hu = reinterpret_cast<uint2*>(lds);                               // [row_cap] {codes, unique}
+    uint16_t* ctab = reinterpret_cast<uint16_t*>(hu + row_cap);             // [kCandSlots]
+    uint32_t* ubits = lds + 2 * row_cap + kCandSlots / 2;                    // [512] one bit per 7-mer value: owned by a unique start
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_thr = blockDim.x;
+    uint32_t* rrow = ubits + kHashSize / 32 + wave * 20;                      // [20] packed read of an undecided pair
+    const int part = tid & 3, slot = tid >> 2, n_slots = n_thr >> 2;          // four lanes per read
+    const int base = 16 * pad;                                               // padded row index of haplotype position 0
+    // A workgroup takes haplotypes blockIdx.x, + gridDim.x, ...: a haplotype's work is a few microseconds, and one
+    // workgroup per haplotype left the chip waiting for workgroups to be started.
+    for (int hb = blockIdx.x; hb < n_vote_haps; hb += gridDim.x) {
+    const int64_t q0 = rec_start[hb], q_end = rec_start[hb + 1];
+    if (q0 == q_end) continue;                       // no pair of this list is on the haplotype
+    const VoteHap H = vh[hb];
+    const uint32_t* hw = hap2 + H.hap2off;
+    const uint32_t* uw = hapU + H.hap2off;
+    const int L = H.len, nk = L - kHashNucs, nw = (L + 15) / 16 + 2;
+
+    const VoteRec none = {0, 0, 0};
+    VoteRec rec = q0 + slot < q_end ? vh_recs[q0 + slot] : none;
+    VoteRec rec_next = q0 + n_slots + slot < q_end ? vh_recs[q0 + n_slots + slot] : none;
+    auto votes_of = [&](const VoteRec& r) { return r.rlen > kHashNucs ? r.rlen - kHashNucs : 0; };   // calign.pyx:143
+    VoteWords5 Q, Q_next;
+    vote5_fetch(Q, read2 + rec.r2off, part, votes_of(rec), (votes_of(rec) + 15) >> 4);
+    vote5_fetch(Q_next, read2 + rec_next.r2off, part, votes_of(rec_next), (votes_of(rec_next) + 15) >> 4);
+
+    for (int w = tid; w < row_cap; w += n_thr) {
+        const int k = w - pad;
+        hu[w] = (k >= 0 && k < nw) ? make_uint2(hw[k], uw[k]) : make_uint2(0u, 0u);
+    }
+    for (int w = tid; w < kHashSize / 32; w += n_thr) ubits[w] = 0u;
+    __syncthreads();
+    for (int i = tid; i < nk; i += n_thr) {
+        const uint2 a = hu[pad + (i >> 4)], b = hu[pad + (i >> 4) + 1];
+        const uint32_t sh = 2u * ((uint32_t)i & 15u);
+        const uint32_t key = __builtin_amdgcn_alignbit(b.x, a.x, sh) & 0x3fffu;
+        ctab[cand_slot(key)] = (uint16_t)i;
+        if ((a.y >> sh) & 1u) atomicOr(&ubits[key >> 5], 1u << (key & 31u));
+    }
+    __syncthreads();
+
+    for (int64_t qb = q0; qb < q_end; qb += n_slots) {
+        const bool mine = qb + slot < q_end;
+        const int nv = mine ? votes_of(rec) : 0;
+        const int n_groups = (nv + 15) >> 4;
+        const VoteRec rec_after = qb + 2 * (int64_t)n_slots + slot < q_end ? vh_recs[qb + 2 * (int64_t)n_slots + slot] : none;
+        const VoteWords5 Qc = Q;
+        Q = Q_next;
+
+        // ---- step 1: candidates from the first and the last eight 7-mers, four look-ups per lane ----
+        int c1, c2;
+        {
+            const int s0 = vote5_window(part, nv), w0 = s0 >> 4, sub = (part >> 1) * 4;
+            int first = kNoCand, last = kNoCand;
+#pragma unroll
+            for (int t = 3; t >= 0; --t) {
+                const int i = s0 + sub + t;
+                int j;
+                const bool ok = cand_lookup(hu, ctab, pad, nk, key_from3(Qc.c, i, w0), j) && i < nv;
+                first = ok ? j - i : first;                                    // (descending t: the smallest valid offset stays)
+                last = ok && last == kNoCand ? j - i : last;                   // the largest valid offset
+            }
+            const int f0 = __builtin_amdgcn_update_dpp(0, first, 0x00, 0xf, 0xf, false);   // quad_perm [0,0,0,0]
+            const int f2 = __builtin_amdgcn_update_dpp(0, first, 0xAA, 0xf, 0xf, false);   // quad_perm [2,2,2,2]
+            const int l1 = __builtin_amdgcn_update_dpp(0, last, 0x55, 0xf, 0xf, false);    // quad_perm [1,1,1,1]
+            const int l3 = __builtin_amdgcn_update_dpp(0, last, 0xFF, 0xf, 0xf, false);    // quad_perm [3,3,3,3]
+            c1 = f0 != kNoCand ? f0 : f2;
+            c2 = l3 != kNoCand ? l3 : l1;
+        }
+        const bool has1 = c1 != kNoCand;
+        const bool has2 = c2 != kNoCand && c2 != c1;
+        int n1 = 0, n2 = 0, n3 = 0, c3 = kNoCand, cover = 0;
+        uint32_t m12[4] = {0u, 0u, 0u, 0u};                                   // offsets that equal the haplotype at c1 or c2
+        bool has3 = false;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int g = part + 4 * j;
+            if (g < n_groups) {
+                const uint32_t vm = group_mask(nv, g);
+                uint32_t ma = 0u, mb = 0u;
+                if (has1) n1 += __popc(vote_bits<true>(hu, Qc.g[j].x, Qc.g[j].y, base + c1 + 16 * g, vm, &ma));
+                if (has2) n2 += __popc(vote_bits<true>(hu, Qc.g[j].x, Qc.g[j].y, base + c2 + 16 * g, vm, &mb));
+                m12[j] = ma | mb;
+                cover += __popc(m12[j]);
+            }
+        }
+        n1 = quad_sum(n1); n2 = quad_sum(n2); cover = quad_sum(cover);
+        int rest = nv - cover;                                                // no other position can hold more votes
+        int top = max(n1, n2);
+        bool undecided = mine && nv > 0;                                      // (nv == 0: nothing votes, calign.pyx:137,140)
+
+        // ---- step 2: a third candidate from the middle (a read with two breakpoints against this haplotype:
+        // an indel of its own beside the haplotype's), then the votes there really are ----
+        if (__any(undecided && !(top > rest))) {
+            const bool again = undecided && !(top > rest);
+            {   // sixteen 7-mers from offset nv / 2 on, four per lane; the first that names a position
+                const int s0 = nv >> 1, w0 = s0 >> 4;
+                int first = kNoCand;
+#pragma unroll
+                for (int t = 3; t >= 0; --t) {
+                    const int i = s0 + 4 * part + t;
+                    int j;
+                    const bool ok = again && cand_lookup(hu, ctab, pad, nk, key_from3(Qc.m, i, w0), j) && i < nv;
+                    first = ok ? j - i : first;
+                }
+                const int m0 = __builtin_amdgcn_update_dpp(0, first, 0x00, 0xf, 0xf, false);
+                const int m1 = __builtin_amdgcn_update_dpp(0, first, 0x55, 0xf, 0xf, false);
+                const int m2 = __builtin_amdgcn_update_dpp(0, first, 0xAA, 0xf, 0xf, false);
+                const int m3 = __builtin_amdgcn_update_dpp(0, first, 0xFF, 0xf, 0xf, false);
+                c3 = m0 != kNoCand ? m0 : m1 != kNoCand ? m1 : m2 != kNoCand ? m2 : m3;
+            }
+            has3 = again && c3 != kNoCand && c3 != c1 && c3 != c2;
+            if (__any(has3)) {
+                int cover3 = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int g = part + 4 * j;
+                    if (g < n_groups && has3) {
+                        uint32_t mc = 0u;
+                        n3 += __popc(vote_bits<true>(hu, Qc.g[j].x, Qc.g[j].y, base + c3 + 16 * g, group_mask(nv, g), &mc));
+                        cover3 += __popc(mc & ~m12[j]);
+                    }
+                }
+                n3 = quad_sum(n3);
+                cover += quad_sum(cover3);
+                if (again) { rest = nv - cover; top = max(top, n3); }
+            }
+            if (__any(again && !(top > rest))) {
+                // not every 7-mer of a read votes (a repeated or absent one does not): the number that do is the other
+                // bound, at one bit look-up per 7-mer
+                const bool still = again && !(top > rest);
+                int tot = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int g = part + 4 * j;
+                    if (still && g < n_groups) {
+                        const uint2 w = Qc.g[j];
+                        uint32_t hits = 0;
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) {
+                            const uint32_t key = (k == 0 ? w.x : __builtin_amdgcn_alignbit(w.y, w.x, 2 * k)) & 0x3fffu;
+                            hits |= ((ubits[key >> 5] >> (key & 31u)) & 1u) << (2 * k);
+                        }
+                        tot += __popc(hits & group_mask(nv, g));
+                    }
+                }
+                tot = quad_sum(tot);
+                if (still) {
+                    rest = min(rest, tot - n1 - n2 - n3);                     // both bound every other position's count
+                    if (tot == 0) undecided = false;                          // nothing votes: position 0 (calign.pyx:137)
+                }
+            }
+        }
+        int winner = 0;
+        bool tie = false;
+        if (top > rest) {
+            undecided = false;
+            const int holders = (int)(has1 && n1 == top) + (int)(has2 && n2 == top) + (int)(has3 && n3 == top);
+            winner = (has1 && n1 == top) ? c1 : (has2 && n2 == top) ? c2 : c3;
+            tie = holders > 1;
+        }
+        if (__any(tie)) {
+            // several candidates reach the final maximum: the one whose last vote comes first got there first
+            int last1 = -1, last2 = -1, last3 = -1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int g = part + 4 * j;
+                if (tie && g < n_groups) {
+                    const uint32_t vm = group_mask(nv, g);
+                    const uint32_t v1 = has1 ? vote_bits(hu, Qc.g[j].x, Qc.g[j].y, base + c1 + 16 * g, vm) : 0u;
+                    const uint32_t v2 = has2 ? vote_bits(hu, Qc.g[j].x, Qc.g[j].y, base + c2 + 16 * g, vm) : 0u;
+                    const uint32_t v3 = has3 ? vote_bits(hu, Qc.g[j].x, Qc.g[j].y, base + c3 + 16 * g, vm) : 0u;
+                    if (v1) last1 = 16 * g + ((31 - __clz((int)v1)) >> 1);
+                    if (v2) last2 = 16 * g + ((31 - __clz((int)v2)) >> 1);
+                    if (v3) last3 = 16 * g + ((31 - __clz((int)v3)) >> 1);
+                }
+            }
+            last1 = quad_max(last1); last2 = quad_max(last2); last3 = quad_max(last3);
+            if (tie) {
+                int best = 0x7fffffff;
+                if (has3 && n3 == top) { best = last3; winner = c3; }
+                if (has2 && n2 == top && last2 < best) { best = last2; winner = c2; }
+                if (has1 && n1 == top && last1 < best) { best = last1; winner = c1; }
+            }
+        }
+        if (mine && part == 0 && !undecided) anchor[rec.pair] = winner - 8 > 0 ? winner - 8 : 0;   // calign.pyx:67
+
+        // ---- steps 3 and 4: the wavefront takes the reads the candidates do not decide, one at a time ----
+        unsigned long long todo = __ballot(undecided && part == 0);
+        while (todo) {
+            const int j = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int pair = __builtin_amdgcn_readlane(rec.pair, j);
+            const int nvj = __builtin_amdgcn_readlane(nv, j);
+            const int ngj = (nvj + 15) >> 4;
+            if ((lane >> 2) == (j >> 2)) {                                     // its words are in its quad's registers
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (part + 4 * k < ngj) { rrow[part + 4 * k] = Qc.g[k].x; rrow[part + 4 * k + 1] = Qc.g[k].y; }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // exact count and last vote of one position; key = count << 16 | (0xffff - last vote): the largest key is
+            // the largest count and, among equal counts, the earliest last vote
+            auto key_of = [&](int cc) -> uint32_t {
+                int n = 0, last = -1;
+                for (int g = 0; g < ngj; ++g) {
+                    const uint32_t v = vote_bits(hu, rrow[g], rrow[g + 1], base + cc + 16 * g, group_mask(nvj, g));
+                    n += __popc(v);
+                    if (v) last = 16 * g + ((31 - __clz((int)v)) >> 1);
+                }
+                return n > 0 ? ((uint32_t)n << 16) | (uint32_t)(0xffff - last) : 0u;
+            };
+            uint32_t best_key = 0;
+            int best_c = 0, lost = 0;
+            for (int i = lane; i < nvj; i += 64) {                             // step 3: the positions this lane's offsets name
+                const uint32_t key = hash7_lds(rrow, i);
+                if ((ubits[key >> 5] >> (key & 31u)) & 1u) {
+                    int jpos;
+                    if (cand_lookup(hu, ctab, pad, nk, key, jpos)) {
+                        const uint32_t k2 = key_of(jpos - i);
+                        if (k2 > best_key) { best_key = k2; best_c = jpos - i; }
+                    } else {
+                        ++lost;                                                // it votes, but for a position this table cannot name
+                    }
+                }
+            }
+            lost = wave_sum(lost);
+            uint32_t wmax = (uint32_t)wave_max_nonneg((int)best_key);          // counts are below 2^15
+            const bool full = (int)(wmax >> 16) <= lost && !(wmax == 0 && lost == 0);
+            if (full) {                                                        // step 4: positions -(nvj - 1) .. nk - 1, all of them
+                best_key = 0;
+                best_c = 0;
+                for (int cc = -(nvj - 1) + lane; cc < nk; cc += 64) {
+                    const uint32_t k2 = key_of(cc);
+                    if (k2 > best_key) { best_key = k2; best_c = cc; }
+                }
+                wmax = (uint32_t)wave_max_nonneg((int)best_key);
+            }
+            const unsigned long long who = __ballot(best_key == wmax);
+            const int win = wmax == 0 ? 0 : __builtin_amdgcn_readlane(best_c, __ffsll((long long)who) - 1);
+            if (lane == 0) {
+                anchor[pair] = win - 8 > 0 ? win - 8 : 0;
+                atomicAdd(&status[full ? 4 : 3], 1);                           // ST_N_FULL / ST_N_NAMED of pg_prep.hip.h
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        rec = rec_next;
+        rec_next = rec_after;
+        vote5_fetch(Q_next, read2 + rec_next.r2off, part, votes_of(rec_next), (votes_of(rec_next) + 15) >> 4);
+    }
+    __syncthreads();                                 // the next haplotype's rows overwrite these
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Stand-alone forms of hash_sequence and map_read (platypus/calign.pyx:99-158)
 // for callers that use them outside alignNoTraceback: the table in the
 // reference's own layout (int32[16384], index = my_hash with the first base in

@@ -31,6 +31,8 @@ namespace pg {
 enum { ST_BAD_PAIR = 0,   // smallest index of a pair that names a haplotype / read outside the batch, else INT32_MAX
        ST_N_WAVES = 1,    // wavefronts of the alignment kernel (ragged batches)
        ST_N_VOTE = 2,     // pairs on indel-bearing haplotypes
+       ST_N_NAMED = 3,    // of those, pairs the anchoring kernel's candidates did not decide: counted over the positions their 7-mers name
+       ST_N_FULL = 4,     //           ... and pairs counted over every position (both per launch)
        ST_WORDS = 16 };
 
 struct PairWork {

@@ -44,6 +44,7 @@ SYMBOLS = {
     "pg_align_pairs": (C.c_int, [C.c_void_p, C.c_int64, _i32p, _i32p, _i32p, _i32p, _f64p]),
     "pg_align_pairs_noalloc": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pg_kernel_time_ms": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
+    "pg_anchor_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "pg_genotype_loglik": (C.c_int, [C.c_void_p, C.c_int64, _i64p, _i64p, _i32p, _f64p]),
     "pg_hash_sequence": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, _i32p]),
     "pg_map_read": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, _i32p, C.POINTER(C.c_int32)]),
@@ -219,6 +220,13 @@ class AlignContext(object):
         ms = C.c_float(0)
         self._check(LIB.pg_kernel_time_ms(self._h, which, C.byref(ms)))
         return ms.value
+
+    def anchor_stats(self):
+        """(pairs the last launch anchored by 7-mer votes; of those: pairs a wavefront counted over the positions their
+        7-mers name; pairs counted over every position)"""
+        a = (C.c_int64 * 3)()
+        self._check(LIB.pg_anchor_stats(self._h, a))
+        return a[0], a[1], a[2]
 
     def valu_int16_peak(self):
         v = C.c_double(0)

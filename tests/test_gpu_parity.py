@@ -76,6 +76,36 @@ def test_synthetic_windows_vs_checker(ctx, kw):
     _check_batch(ctx, synth.make_batch(**kw))
 
 
+@pytest.mark.parametrize("kernel", ["bits", "table"])
+@pytest.mark.parametrize("kw", [
+    dict(n_windows=40, read_len=150, indel_hap_frac=1.0, seed=31),
+    # reads the candidate positions cannot decide (a tenth of the bases wrong, every other read with an indel of its
+    # own): the exact count over every position
+    dict(n_windows=24, read_len=150, indel_hap_frac=1.0, sub_rate=0.1, read_indel_frac=0.5, seed=32),
+    dict(n_windows=24, read_len=100, indel_hap_frac=1.0, homopolymers=True, n_frac=0.05, sub_rate=0.1, seed=33),
+    dict(n_windows=12, read_len=263, hap_len=1500, indel_hap_frac=1.0, reads_per_window=70, sub_rate=0.05, seed=34),
+    dict(n_windows=30, read_len=40, hap_len=200, indel_hap_frac=1.0, ragged=True, sub_rate=0.1, seed=35),
+    dict(n_windows=6, read_len=150, haps_per_window=12, reads_per_window=300, indel_hap_frac=1.0, seed=36),
+])
+def test_both_anchoring_kernels(kernel, kw):
+    """the 7-mer anchoring by exact bit-parallel counts (the default for reads of up to 263 bases) and by the
+    position table in LDS: the reference's anchors from either"""
+    from platypus_amd import native, synth
+    c = native.AlignContext(0, 512)
+    try:
+        c.set_option("vote_kernel", kernel)
+        b = synth.make_batch(**kw)
+        rng = np.random.default_rng(kw["seed"])
+        # some reads moved off their place, a few far off either end of the haplotypes
+        nR = len(b["read_pos"])
+        shift = np.where(rng.random(nR) < 0.15, rng.integers(-40, 41, nR), 0)
+        shift = np.where(rng.random(nR) < 0.03, rng.integers(-kw.get("hap_len", 750), kw.get("hap_len", 750), nR), shift)
+        b["read_pos"] = (b["read_pos"].astype(np.int64) + shift).astype(np.int32)
+        _check_batch(c, b)
+    finally:
+        c.close()
+
+
 def test_edge_cases(ctx):
     """Short reads, reads running off the haplotype end on both paths, a
     haplotype shorter than a 7-mer, repeated 7-mers only, no votes."""
