@@ -101,8 +101,7 @@ int pg_set_params(pg_ctx *ctx, int gapextend, int nucprior, const char *table, i
  *   "em_stage_max"   doubles of one window the "big" EM kernel may keep in LDS
  *   "em_step"        full | sym            the "multi" path's step reads whole matrices or their upper triangle
  *   "em_step_waves"  1..16 wavefronts per workgroup of the triangle step
- *   "vote_waves"     1..4 wavefronts per workgroup of the anchoring kernel
- *   "vote_grid"      workgroups of the bit-parallel anchoring kernel (each loops over haplotypes)
+ *   "vote_waves"     1..4 wavefronts per workgroup of the anchoring kernel (bit-parallel kernel: 64 pairs each)
  *   "vote_kernel"    table | bits          anchoring by a 16384-entry position table per haplotype in LDS, or by exact
  *                                          bit-parallel counts for candidate positions (the default for reads of up to
  *                                          263 bases; longer reads always take the table)

@@ -537,7 +537,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // One workgroup per haplotype; the 16384-entry table of the reference in LDS.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_hap_unique(const uint32_t* __restrict__ hap2, const VoteHap* __restrict__ vh,
-                                                    uint32_t* __restrict__ hapU)
+                                                    uint32_t* __restrict__ hapU, uint32_t* __restrict__ hapUbits)
 {
     __shared__ uint16_t tab[kHashSize];
     const int tid = threadIdx.x;
@@ -566,6 +566,13 @@ __global__ __launch_bounds__(256) void k_hap_unique(const uint32_t* __restrict__
         }
         hapU[H.hap2off + w] = bits;
     }
+    // ... and which 7-mer VALUES are owned by a unique start: one bit per value, 512 words per haplotype
+    for (int w = tid; w < kHashSize / 32; w += 256) {
+        uint32_t bits = 0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) bits |= (uint32_t)(tab[32 * w + k] != 0xffffu) << k;
+        hapUbits[(size_t)blockIdx.x * (kHashSize / 32) + w] = bits;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -579,41 +586,43 @@ __global__ __launch_bounds__(256) void k_hap_unique(const uint32_t* __restrict__
 // (three and-with-shift steps), and with the uniqueness row at the same shift,
 // popcount.  Exact counts n_k for a few candidate positions decide a read as the
 // reference does whenever the best of them beats every vote that is not theirs:
-//   top = max n_k  >  rest = (voting 7-mers of the read) - sum n_k  >=  any other count
+//   top = max n_k  >  rest  >=  any other position's count
 // (ties between candidates: the one whose last vote comes first reached the final
-// maximum first, platypus/calign.pyx:150-153).  Candidates only have to be GOOD,
-// not exact: they come from a small direct-mapped table of the haplotype's 7-mer
-// starts (4096 x u16, last writer wins, never cleared; every hit is verified
-// against the haplotype's rows).  Four lanes per read, four steps, each taken only
-// by the wavefronts that still hold an undecided read:
-//   1  candidates from the read's first and last eight 7-mers; rest bounded by the
-//      number of the read's 7-mers that do not equal the haplotype's at any
-//      candidate's place (one that does votes there or, repeated, nowhere)
-//   2  rest from the number of 7-mers that vote at all (one bit per 7-mer value:
-//      owned by a unique start), and a third candidate from the read's middle
-//   3  the wavefront takes the read: every lane counts the positions its own
-//      offsets name; a position nobody could name (its table slot was taken by
-//      another 7-mer) holds at most `lost` votes, so the best count decides when
-//      it is above that
-//   4  the count for EVERY position: largest count, earliest last vote
-// LDS per workgroup: the haplotype's code and uniqueness words, zero-padded by a
-// read length on both sides (no shift needs a bounds test), the candidate table
-// (8 KiB), the bit set (2 KiB) and one packed read per wavefront.
+// maximum first, platypus/calign.pyx:150-153).  rest is bounded two ways: an
+// offset whose 7-mer EQUALS the haplotype's at a candidate's place votes there or,
+// if that 7-mer is repeated, nowhere -- so only the other offsets can vote
+// elsewhere; and only 7-mers owned by a unique start vote at all (one bit per
+// 7-mer value, made at upload).  Candidates only have to be GOOD, not exact: they
+// come from a small direct-mapped table of the haplotype's 7-mer starts (2048 x
+// u16, last writer wins, never cleared; every hit is verified against the
+// haplotype's rows), looked up for four 7-mers each from the read's start, middle
+// and end (a read with an indel of its own against an indel-bearing haplotype has
+// three stretches).
+//
+// ONE LANE PER PAIR.  A workgroup takes the next blockDim.x vote records (they
+// are grouped by haplotype) and, four haplotypes at a time, puts their rows and
+// candidate tables side by side in LDS; every lane whose record is on one of them
+// then works alone: twelve look-ups, three exact counts over its read's groups.
+// (Four lanes per pair with the groups dealt between them cost two to three times
+// the instructions per pair: per-lane overheads, uneven shares, combining steps.)
+// What stays undecided is taken by the whole wavefront, one read at a time:
+//   a  every lane counts the positions its own offsets name; a position nobody
+//      could name (its table slot was taken by another 7-mer) holds at most
+//      `lost` votes, so the best count decides when it is above that
+//   b  the count for EVERY position: largest count, earliest last vote
 // Reads of up to 263 bases (sixteen 16-base groups, in registers); the host
 // sends launches with longer reads to k_vote4.
 // ---------------------------------------------------------------------------
-constexpr int kCandSlots = 4096;
+constexpr int kCandSlots = 2048;
 constexpr int kNoCand = 0x40000000;
+constexpr int kVoteSlots = 4;        // haplotypes side by side in LDS
 
-__device__ __forceinline__ uint32_t cand_slot(uint32_t key) { return (key ^ (key >> 7)) & (uint32_t)(kCandSlots - 1); }
+__device__ __forceinline__ uint32_t cand_slot(uint32_t key) { return (key ^ (key >> 6)) & (uint32_t)(kCandSlots - 1); }
 
 // votes of read offsets 16 g .. 16 g + 15 (read words rl, rh = offsets 16 g .. 16 g + 31) for the position whose
 // offset-16g base sits at padded row index s; result: bit 2 k set = offset 16 g + k votes (vm: offsets that exist).
-// An offset whose 7-mer merely EQUALS the haplotype's there (`matches`) votes for no other position either: a
-// unique 7-mer votes for this one, a repeated one for none.
-template <bool MATCHES = false>
-__device__ __forceinline__ uint32_t vote_bits(const uint2* __restrict__ hu, uint32_t rl, uint32_t rh, int s, uint32_t vm,
-                                              uint32_t* matches = nullptr)
+// `matches`: offsets whose 7-mer equals the haplotype's there, unique or not.
+__device__ __forceinline__ uint32_t vote_bits(const uint2* hu, uint32_t rl, uint32_t rh, int s, uint32_t vm, uint32_t& matches)
 {
     const int wi = s >> 4;
     const uint32_t sh = 2u * ((uint32_t)s & 15u);
@@ -624,9 +633,8 @@ __device__ __forceinline__ uint32_t vote_bits(const uint2* __restrict__ hu, uint
     const uint32_t el = ~(xl | (xl >> 1)), eh = ~(xh | (xh >> 1));           // even bits: bases equal
     const uint32_t a1l = el & __builtin_amdgcn_alignbit(eh, el, 2), a1h = eh & (eh >> 2);          // runs of 2
     const uint32_t a2l = a1l & __builtin_amdgcn_alignbit(a1h, a1l, 4), a2h = a1h & (a1h >> 4);    // runs of 4
-    const uint32_t m7 = a2l & __builtin_amdgcn_alignbit(a2h, a2l, 6) & vm;                         // runs of 7
-    if (MATCHES) *matches = m7;                 // the read's 7-mer is the haplotype's at that place, unique or not
-    return m7 & u;
+    matches = a2l & __builtin_amdgcn_alignbit(a2h, a2l, 6) & vm;                                    // runs of 7
+    return matches & u;
 }
 
 __device__ __forceinline__ uint32_t group_mask(int nv, int g) {           // offsets 16 g + k < nv
@@ -636,46 +644,13 @@ __device__ __forceinline__ uint32_t group_mask(int nv, int g) {           // off
 
 // start of the haplotype's 7-mer `key` according to the candidate table; true if the haplotype really holds the
 // 7-mer there and that start owns it alone
-__device__ __forceinline__ bool cand_lookup(const uint2* __restrict__ hu, const uint16_t* __restrict__ ctab, int pad, int nk,
-                                            uint32_t key, int& j)
+__device__ __forceinline__ bool cand_lookup(const uint2* hu, const uint16_t* ctab, int pad, int nk, uint32_t key, int& j)
 {
-    j = (int)ctab[cand_slot(key)];
-    const int jj = j < nk ? j : 0;                                            // (a slot nobody wrote holds anything)
-    const uint2 a = hu[pad + (jj >> 4)], b = hu[pad + (jj >> 4) + 1];
-    const uint32_t sh = 2u * ((uint32_t)jj & 15u);
+    j = min((int)ctab[cand_slot(key)], nk - 1);                              // (a slot nobody wrote holds anything)
+    const uint2 a = hu[pad + (j >> 4)], b = hu[pad + (j >> 4) + 1];
+    const uint32_t sh = 2u * ((uint32_t)j & 15u);
     const uint32_t hk = __builtin_amdgcn_alignbit(b.x, a.x, sh) & 0x3fffu;
-    return j < nk && hk == key && ((a.y >> sh) & 1u);
-}
-
-// window of eight 7-mers a lane of a read's quad looks at for the first two candidates: lanes 0 and 2 the read's
-// first eight (four each), lanes 1 and 3 its last eight
-__device__ __forceinline__ int vote5_window(int part, int nv) { return (part & 1) && nv > 8 ? nv - 8 : 0; }
-
-struct VoteWords5 {
-    uint2 g[4];        // word pairs of the lane's groups part, part + 4, part + 8, part + 12
-    uint32_t c[3];     // the words of its candidate window
-    uint32_t m[3];     // the words of the middle window (sixteen 7-mers from offset nv / 2 on)
-};
-
-__device__ __forceinline__ void vote5_fetch(VoteWords5& Q, const uint32_t* __restrict__ rw, int part, int nv, int n_groups)
-{
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        Q.g[j] = make_uint2(0, 0);
-        if (part + 4 * j < n_groups) __builtin_memcpy(&Q.g[j], rw + part + 4 * j, 8);
-    }
-    Q.c[0] = Q.c[1] = Q.c[2] = Q.m[0] = Q.m[1] = Q.m[2] = 0;
-    if (nv > 0) {
-        __builtin_memcpy(Q.c, rw + (vote5_window(part, nv) >> 4), 12);
-        __builtin_memcpy(Q.m, rw + ((nv >> 1) >> 4), 12);
-    }
-}
-
-// the 7-mer at read offset i from the three words that start at word w0
-__device__ __forceinline__ uint32_t key_from3(const uint32_t* c, int i, int w0) {
-    const int bit = 2 * (i - 16 * w0);                                        // 0 .. 62
-    const uint32_t lo = bit < 32 ? c[0] : c[1], hi = bit < 32 ? c[1] : c[2];
-    return __builtin_amdgcn_alignbit(hi, lo, bit & 31) & 0x3fffu;
+    return (hk == key) & (bool)((a.y >> sh) & 1u);
 }
 
 __device__ __forceinline__ int wave_sum(int v) {
@@ -684,166 +659,213 @@ __device__ __forceinline__ int wave_sum(int v) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void k_vote5(const uint32_t* __restrict__ hap2, const uint32_t* __restrict__ hapU,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_vote5(const uint32_t* __restrict__ hap2, const uint32_t* __restrict__ hapU,
+                                               const uint32_t* __restrict__ hapUbits,
                                                const uint32_t* __restrict__ read2, const VoteHap* __restrict__ vh,
                                                const int32_t* __restrict__ rec_start, const VoteRec* __restrict__ vh_recs,
                                                int32_t* __restrict__ status, int32_t* __restrict__ anchor,
                                                int pad, int row_cap, int n_vote_haps)
 {
     if (status[0] != 0x7fffffff) return;             // nothing runs on a list with an index out of range
-    extern __shared__ uint32_t lds[];
-    uint2* hu = reinterpret_cast<uint2*>(lds);                               // [row_cap] {codes, unique}
-    uint16_t* ctab = reinterpret_cast<uint16_t*>(hu + row_cap);             // [kCandSlots]
-    uint32_t* ubits = lds + 2 * row_cap + kCandSlots / 2;                    // [512] one bit per 7-mer value: owned by a unique start
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_thr = blockDim.x;
-    uint32_t* rrow = ubits + kHashSize / 32 + wave * 20;                      // [20] packed read of an undecided pair
-    const int part = tid & 3, slot = tid >> 2, n_slots = n_thr >> 2;          // four lanes per read
+    const int64_t n_recs = rec_start[n_vote_haps];
+    const int64_t r0 = (int64_t)blockIdx.x * n_thr, r1 = min(r0 + (int64_t)n_thr, n_recs);
+    if (r0 >= n_recs) return;
+    extern __shared__ uint32_t lds[];
+    const int slot_words = 2 * row_cap + kCandSlots / 2;                     // a haplotype's rows {codes, unique} and its table
+    uint32_t* rrow = lds + kVoteSlots * slot_words + wave * 20;              // [20] packed read of an undecided pair
     const int base = 16 * pad;                                               // padded row index of haplotype position 0
-    // A workgroup takes haplotypes blockIdx.x, + gridDim.x, ...: a haplotype's work is a few microseconds, and one
-    // workgroup per haplotype left the chip waiting for workgroups to be started.
-    for (int hb = blockIdx.x; hb < n_vote_haps; hb += gridDim.x) {
-    const int64_t q0 = rec_start[hb], q_end = rec_start[hb + 1];
-    if (q0 == q_end) continue;                       // no pair of this list is on the haplotype
-    const VoteHap H = vh[hb];
-    const uint32_t* hw = hap2 + H.hap2off;
-    const uint32_t* uw = hapU + H.hap2off;
-    const int L = H.len, nk = L - kHashNucs, nw = (L + 15) / 16 + 2;
 
-    const VoteRec none = {0, 0, 0};
-    VoteRec rec = q0 + slot < q_end ? vh_recs[q0 + slot] : none;
-    VoteRec rec_next = q0 + n_slots + slot < q_end ? vh_recs[q0 + n_slots + slot] : none;
-    auto votes_of = [&](const VoteRec& r) { return r.rlen > kHashNucs ? r.rlen - kHashNucs : 0; };   // calign.pyx:143
-    VoteWords5 Q, Q_next;
-    vote5_fetch(Q, read2 + rec.r2off, part, votes_of(rec), (votes_of(rec) + 15) >> 4);
-    vote5_fetch(Q_next, read2 + rec_next.r2off, part, votes_of(rec_next), (votes_of(rec_next) + 15) >> 4);
-
-    for (int w = tid; w < row_cap; w += n_thr) {
-        const int k = w - pad;
-        hu[w] = (k >= 0 && k < nw) ? make_uint2(hw[k], uw[k]) : make_uint2(0u, 0u);
+    // my record and my read
+    const int64_t my = r0 + tid;
+    const bool have = my < r1;
+    const VoteRec rec = have ? vh_recs[my] : VoteRec{0, 0, 0};
+    const int nv = rec.rlen > kHashNucs ? rec.rlen - kHashNucs : 0;          // calign.pyx:143
+    const int n_groups = (nv + 15) >> 4;
+    uint32_t rw[17];
+    // the three words that hold the 7-mers looked at near the read's end (offsets nv - 16 .. nv - 1) and in its middle
+    // (nv / 2 .. + 15): fetched on their own, a register array cannot be indexed by a lane's own number
+    const int e0 = nv > 16 ? nv - 16 : 0, m0 = nv >> 1, we = e0 >> 4, wm = m0 >> 4;
+    uint32_t ew[3] = {0u, 0u, 0u}, mw[3] = {0u, 0u, 0u};
+    {
+        const uint32_t* src = read2 + rec.r2off;
+#pragma unroll
+        for (int k = 0; k < 17; ++k) rw[k] = (have && k <= n_groups && nv > 0) ? src[k] : 0u;
+        if (have && nv > 0) {                          // (rows end with two zero words: we + 2 <= n_groups + 1)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { ew[k] = src[min(we + k, n_groups + 1)]; mw[k] = src[min(wm + k, n_groups + 1)]; }
+        }
     }
-    for (int w = tid; w < kHashSize / 32; w += n_thr) ubits[w] = 0u;
-    __syncthreads();
-    for (int i = tid; i < nk; i += n_thr) {
-        const uint2 a = hu[pad + (i >> 4)], b = hu[pad + (i >> 4) + 1];
-        const uint32_t sh = 2u * ((uint32_t)i & 15u);
-        const uint32_t key = __builtin_amdgcn_alignbit(b.x, a.x, sh) & 0x3fffu;
-        ctab[cand_slot(key)] = (uint16_t)i;
-        if ((a.y >> sh) & 1u) atomicOr(&ubits[key >> 5], 1u << (key & 31u));
+    const int ng_max = wave_max_nonneg(n_groups);
+
+    // first haplotype with a record at or behind r0: the last h with rec_start[h] <= r0
+    int h0;
+    {
+        int lo = 0, hi = n_vote_haps;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (rec_start[mid] <= r0) lo = mid; else hi = mid;
+        }
+        h0 = lo;
     }
-    __syncthreads();
-
-    for (int64_t qb = q0; qb < q_end; qb += n_slots) {
-        const bool mine = qb + slot < q_end;
-        const int nv = mine ? votes_of(rec) : 0;
-        const int n_groups = (nv + 15) >> 4;
-        const VoteRec rec_after = qb + 2 * (int64_t)n_slots + slot < q_end ? vh_recs[qb + 2 * (int64_t)n_slots + slot] : none;
-        const VoteWords5 Qc = Q;
-        Q = Q_next;
-
-        // ---- step 1: candidates from the first and the last eight 7-mers, four look-ups per lane ----
-        int c1, c2;
+    bool done = !have;
+    for (int hb = h0; hb < n_vote_haps && rec_start[hb] < r1; hb += kVoteSlots) {
+        if (hb != h0) __syncthreads();               // everybody has left the slots
+        // ---- the next haplotypes' rows and candidate tables, a share of the workgroup's threads on each ----
+        int n_live = 0;
+#pragma unroll
+        for (int k = 0; k < kVoteSlots; ++k)
+            n_live += (int)(hb + k < n_vote_haps && rec_start[hb + k] < r1 && rec_start[hb + k + 1] > rec_start[hb + k] &&
+                            rec_start[hb + k + 1] > r0);
+        // (the haplotypes with records of mine are the first n_live or fewer of the four: one without records in
+        // between takes a share of the threads for nothing, no more)
+        const int per = n_thr / max(1, min(kVoteSlots, n_live == kVoteSlots ? kVoteSlots : n_live)), sl0 = tid / per;
+        const int st = tid - sl0 * per;
+        int sl = -1;                                   // the sl0-th live slot
         {
-            const int s0 = vote5_window(part, nv), w0 = s0 >> 4, sub = (part >> 1) * 4;
-            int first = kNoCand, last = kNoCand;
+            int seen = 0;
 #pragma unroll
-            for (int t = 3; t >= 0; --t) {
-                const int i = s0 + sub + t;
-                int j;
-                const bool ok = cand_lookup(hu, ctab, pad, nk, key_from3(Qc.c, i, w0), j) && i < nv;
-                first = ok ? j - i : first;                                    // (descending t: the smallest valid offset stays)
-                last = ok && last == kNoCand ? j - i : last;                   // the largest valid offset
-            }
-            const int f0 = __builtin_amdgcn_update_dpp(0, first, 0x00, 0xf, 0xf, false);   // quad_perm [0,0,0,0]
-            const int f2 = __builtin_amdgcn_update_dpp(0, first, 0xAA, 0xf, 0xf, false);   // quad_perm [2,2,2,2]
-            const int l1 = __builtin_amdgcn_update_dpp(0, last, 0x55, 0xf, 0xf, false);    // quad_perm [1,1,1,1]
-            const int l3 = __builtin_amdgcn_update_dpp(0, last, 0xFF, 0xf, 0xf, false);    // quad_perm [3,3,3,3]
-            c1 = f0 != kNoCand ? f0 : f2;
-            c2 = l3 != kNoCand ? l3 : l1;
-        }
-        const bool has1 = c1 != kNoCand;
-        const bool has2 = c2 != kNoCand && c2 != c1;
-        int n1 = 0, n2 = 0, n3 = 0, c3 = kNoCand, cover = 0;
-        uint32_t m12[4] = {0u, 0u, 0u, 0u};                                   // offsets that equal the haplotype at c1 or c2
-        bool has3 = false;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int g = part + 4 * j;
-            if (g < n_groups) {
-                const uint32_t vm = group_mask(nv, g);
-                uint32_t ma = 0u, mb = 0u;
-                if (has1) n1 += __popc(vote_bits<true>(hu, Qc.g[j].x, Qc.g[j].y, base + c1 + 16 * g, vm, &ma));
-                if (has2) n2 += __popc(vote_bits<true>(hu, Qc.g[j].x, Qc.g[j].y, base + c2 + 16 * g, vm, &mb));
-                m12[j] = ma | mb;
-                cover += __popc(m12[j]);
+            for (int k = 0; k < kVoteSlots; ++k) {
+                const bool lv = hb + k < n_vote_haps && rec_start[hb + k] < r1 && rec_start[hb + k + 1] > rec_start[hb + k] &&
+                                rec_start[hb + k + 1] > r0;
+                if (lv && seen == sl0 && sl < 0) sl = k;
+                seen += (int)lv;
             }
         }
-        n1 = quad_sum(n1); n2 = quad_sum(n2); cover = quad_sum(cover);
-        int rest = nv - cover;                                                // no other position can hold more votes
-        int top = max(n1, n2);
-        bool undecided = mine && nv > 0;                                      // (nv == 0: nothing votes, calign.pyx:137,140)
+        const bool live = sl >= 0;
+        if (sl < 0) sl = 0;
+        const int hs = hb + sl;
+        {
+            uint2* hu = reinterpret_cast<uint2*>(lds + sl * slot_words);
+            if (live) {
+                const VoteHap H = vh[hs];
+                const uint32_t* hw = hap2 + H.hap2off;
+                const uint32_t* uw = hapU + H.hap2off;
+                const int nw = (H.len + 15) / 16 + 2;
+                for (int w = st; w < row_cap; w += per) {
+                    const int k = w - pad;
+                    hu[w] = (k >= 0 && k < nw) ? make_uint2(hw[k], uw[k]) : make_uint2(0u, 0u);
+                }
+            }
+        }
+        __syncthreads();
+        if (live) {
+            const uint2* hu = reinterpret_cast<const uint2*>(lds + sl * slot_words);
+            uint16_t* ctab = reinterpret_cast<uint16_t*>(lds + sl * slot_words + 2 * row_cap);
+            const int nk = vh[hs].len - kHashNucs;
+            for (int i = st; i < nk; i += per) {
+                const uint2 a = hu[pad + (i >> 4)], b = hu[pad + (i >> 4) + 1];
+                const uint32_t key = __builtin_amdgcn_alignbit(b.x, a.x, 2u * ((uint32_t)i & 15u)) & 0x3fffu;
+                ctab[cand_slot(key)] = (uint16_t)i;
+            }
+        }
+        __syncthreads();
 
-        // ---- step 2: a third candidate from the middle (a read with two breakpoints against this haplotype:
-        // an indel of its own beside the haplotype's), then the votes there really are ----
-        if (__any(undecided && !(top > rest))) {
-            const bool again = undecided && !(top > rest);
-            {   // sixteen 7-mers from offset nv / 2 on, four per lane; the first that names a position
-                const int s0 = nv >> 1, w0 = s0 >> 4;
-                int first = kNoCand;
+        // ---- which of these haplotypes is mine? ----
+        int myslot = -1;
 #pragma unroll
-                for (int t = 3; t >= 0; --t) {
-                    const int i = s0 + 4 * part + t;
-                    int j;
-                    const bool ok = again && cand_lookup(hu, ctab, pad, nk, key_from3(Qc.m, i, w0), j) && i < nv;
-                    first = ok ? j - i : first;
-                }
-                const int m0 = __builtin_amdgcn_update_dpp(0, first, 0x00, 0xf, 0xf, false);
-                const int m1 = __builtin_amdgcn_update_dpp(0, first, 0x55, 0xf, 0xf, false);
-                const int m2 = __builtin_amdgcn_update_dpp(0, first, 0xAA, 0xf, 0xf, false);
-                const int m3 = __builtin_amdgcn_update_dpp(0, first, 0xFF, 0xf, 0xf, false);
-                c3 = m0 != kNoCand ? m0 : m1 != kNoCand ? m1 : m2 != kNoCand ? m2 : m3;
+        for (int k = 0; k < kVoteSlots; ++k) {
+            const int h = hb + k;
+            if (h < n_vote_haps && !done && my >= rec_start[h] && my < rec_start[h + 1]) myslot = k;
+        }
+        const bool active = myslot >= 0;
+        if (!__any(active)) continue;
+        const int slot_i = active ? myslot : 0, hm = hb + slot_i;
+        const uint2* hu = reinterpret_cast<const uint2*>(lds + slot_i * slot_words);
+        const uint16_t* ctab = reinterpret_cast<const uint16_t*>(lds + slot_i * slot_words + 2 * row_cap);
+        const int nk = vh[min(hm, n_vote_haps - 1)].len - kHashNucs;
+        if (active) done = true;
+
+        // ---- candidates: four 7-mers each from the read's start, middle and end, five bases apart (a wrong base
+        // spoils at most two of a window's four) ----
+        int c1 = kNoCand, c2 = kNoCand, c3 = kNoCand;
+        {
+            auto key3 = [&](uint32_t lo, uint32_t hi, uint32_t top, int bit) -> uint32_t {     // bit: 0 .. 60
+                const uint32_t x = bit < 32 ? lo : hi, y = bit < 32 ? hi : top;
+                return __builtin_amdgcn_alignbit(y, x, bit & 31) & 0x3fffu;
+            };
+#pragma unroll
+            for (int t = 3; t >= 0; --t) {                 // start: offsets 0, 5, 10, 15; the smallest that names a position
+                int j;
+                const bool ok = cand_lookup(hu, ctab, pad, nk, key3(rw[0], rw[1], rw[2], 10 * t), j) & (5 * t < nv);
+                c1 = ok ? j - 5 * t : c1;
             }
-            has3 = again && c3 != kNoCand && c3 != c1 && c3 != c2;
-            if (__any(has3)) {
-                int cover3 = 0;
+            const uint32_t e_lo = ew[0], e_hi = ew[1], e_top = ew[2], m_lo = mw[0], m_hi = mw[1], m_top = mw[2];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int g = part + 4 * j;
-                    if (g < n_groups && has3) {
-                        uint32_t mc = 0u;
-                        n3 += __popc(vote_bits<true>(hu, Qc.g[j].x, Qc.g[j].y, base + c3 + 16 * g, group_mask(nv, g), &mc));
-                        cover3 += __popc(mc & ~m12[j]);
-                    }
-                }
-                n3 = quad_sum(n3);
-                cover += quad_sum(cover3);
-                if (again) { rest = nv - cover; top = max(top, n3); }
+            for (int t = 0; t < 4; ++t) {                  // end: offsets nv - 16, - 11, - 6, - 1; the largest that names one
+                const int i = e0 + 5 * t;
+                int j;
+                const bool ok = cand_lookup(hu, ctab, pad, nk, key3(e_lo, e_hi, e_top, 2 * (i - 16 * we)), j) & (i < nv);
+                c2 = ok ? j - i : c2;
             }
-            if (__any(again && !(top > rest))) {
-                // not every 7-mer of a read votes (a repeated or absent one does not): the number that do is the other
-                // bound, at one bit look-up per 7-mer
-                const bool still = again && !(top > rest);
-                int tot = 0;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int g = part + 4 * j;
-                    if (still && g < n_groups) {
-                        const uint2 w = Qc.g[j];
-                        uint32_t hits = 0;
+            for (int t = 3; t >= 0; --t) {                 // middle: nv / 2 + 0, 5, 10, 15; the smallest
+                const int i = m0 + 5 * t;
+                int j;
+                const bool ok = cand_lookup(hu, ctab, pad, nk, key3(m_lo, m_hi, m_top, 2 * (i - 16 * wm)), j) & (i < nv);
+                c3 = ok ? j - i : c3;
+            }
+        }
+        const bool has1 = active && c1 != kNoCand;
+        const bool has2 = active && c2 != kNoCand && c2 != c1;
+        const bool has3 = active && c3 != kNoCand && c3 != c1 && c3 != c2;
+        const int s1 = base + (has1 ? c1 : 0), s2 = base + (has2 ? c2 : 0), s3 = base + (has3 ? c3 : 0);
+        const bool any2 = __any(has2), any3 = __any(has3);
+
+        // ---- exact counts of the candidates over the read's 16-offset groups.  Group g of a candidate needs the
+        // haplotype words g, g + 1, g + 2 from its place on (same shift for every group) and the "equal" bits of two
+        // read words: one new LDS word and one new xor per group and candidate, the rest slides ----
+        int n1 = 0, n2 = 0, n3 = 0, cover = 0;
+        {
+            const uint2* hp1 = hu + (s1 >> 4); const uint2* hp2 = hu + (s2 >> 4); const uint2* hp3 = hu + (s3 >> 4);
+            const uint32_t sh1 = 2u * ((uint32_t)s1 & 15u), sh2 = 2u * ((uint32_t)s2 & 15u), sh3 = 2u * ((uint32_t)s3 & 15u);
+            uint2 A1 = hp1[0], B1 = hp1[1], A2 = hp2[0], B2 = hp2[1], A3 = hp3[0], B3 = hp3[1];
+            auto eq = [](uint32_t x) -> uint32_t { return ~(x | (x >> 1)); };          // even bits: bases equal
+            uint32_t el1 = eq(rw[0] ^ __builtin_amdgcn_alignbit(B1.x, A1.x, sh1));
+            uint32_t el2 = eq(rw[0] ^ __builtin_amdgcn_alignbit(B2.x, A2.x, sh2));
+            uint32_t el3 = eq(rw[0] ^ __builtin_amdgcn_alignbit(B3.x, A3.x, sh3));
+            auto runs7 = [](uint32_t el, uint32_t eh) -> uint32_t {
+                const uint32_t a1l = el & __builtin_amdgcn_alignbit(eh, el, 2), a1h = eh & (eh >> 2);          // runs of 2
+                const uint32_t a2l = a1l & __builtin_amdgcn_alignbit(a1h, a1l, 4), a2h = a1h & (a1h >> 4);    // runs of 4
+                return a2l & __builtin_amdgcn_alignbit(a2h, a2l, 6);                                          // runs of 7
+            };
 #pragma unroll
-                        for (int k = 0; k < 16; ++k) {
-                            const uint32_t key = (k == 0 ? w.x : __builtin_amdgcn_alignbit(w.y, w.x, 2 * k)) & 0x3fffu;
-                            hits |= ((ubits[key >> 5] >> (key & 31u)) & 1u) << (2 * k);
-                        }
-                        tot += __popc(hits & group_mask(nv, g));
+            for (int g = 0; g < 16; ++g) {
+                if (g < ng_max) {
+                    const uint32_t vm = group_mask(nv, g);
+                    uint32_t mm;
+                    {
+                        const uint2 C = hp1[g + 2];
+                        const uint32_t eh = eq(rw[g + 1] ^ __builtin_amdgcn_alignbit(C.x, B1.x, sh1));
+                        const uint32_t m = runs7(el1, eh) & (has1 ? vm : 0u);
+                        n1 += __popc(m & __builtin_amdgcn_alignbit(B1.y, A1.y, sh1));
+                        mm = m;
+                        A1 = B1; B1 = C; el1 = eh;
                     }
-                }
-                tot = quad_sum(tot);
-                if (still) {
-                    rest = min(rest, tot - n1 - n2 - n3);                     // both bound every other position's count
-                    if (tot == 0) undecided = false;                          // nothing votes: position 0 (calign.pyx:137)
+                    if (any2) {
+                        const uint2 C = hp2[g + 2];
+                        const uint32_t eh = eq(rw[g + 1] ^ __builtin_amdgcn_alignbit(C.x, B2.x, sh2));
+                        const uint32_t m = runs7(el2, eh) & (has2 ? vm : 0u);
+                        n2 += __popc(m & __builtin_amdgcn_alignbit(B2.y, A2.y, sh2));
+                        mm |= m;
+                        A2 = B2; B2 = C; el2 = eh;
+                    }
+                    if (any3) {
+                        const uint2 C = hp3[g + 2];
+                        const uint32_t eh = eq(rw[g + 1] ^ __builtin_amdgcn_alignbit(C.x, B3.x, sh3));
+                        const uint32_t m = runs7(el3, eh) & (has3 ? vm : 0u);
+                        n3 += __popc(m & __builtin_amdgcn_alignbit(B3.y, A3.y, sh3));
+                        mm |= m;
+                        A3 = B3; B3 = C; el3 = eh;
+                    }
+                    cover += __popc(mm);
                 }
             }
         }
+        int rest = nv - cover;                                                // no other position can hold more votes
+        const int top = max(n1, max(n2, n3));
+        bool undecided = active && nv > 0;                                    // (nv == 0: nothing votes, calign.pyx:137,140)
+
         int winner = 0;
         bool tie = false;
         if (top > rest) {
@@ -856,19 +878,18 @@ __global__ __launch_bounds__(256) void k_vote5(const uint32_t* __restrict__ hap2
             // several candidates reach the final maximum: the one whose last vote comes first got there first
             int last1 = -1, last2 = -1, last3 = -1;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int g = part + 4 * j;
-                if (tie && g < n_groups) {
-                    const uint32_t vm = group_mask(nv, g);
-                    const uint32_t v1 = has1 ? vote_bits(hu, Qc.g[j].x, Qc.g[j].y, base + c1 + 16 * g, vm) : 0u;
-                    const uint32_t v2 = has2 ? vote_bits(hu, Qc.g[j].x, Qc.g[j].y, base + c2 + 16 * g, vm) : 0u;
-                    const uint32_t v3 = has3 ? vote_bits(hu, Qc.g[j].x, Qc.g[j].y, base + c3 + 16 * g, vm) : 0u;
+            for (int g = 0; g < 16; ++g) {
+                if (g < ng_max) {
+                    const uint32_t vm = tie ? group_mask(nv, g) : 0u;
+                    uint32_t mm;
+                    const uint32_t v1 = vote_bits(hu, rw[g], rw[g + 1], s1 + 16 * g, has1 ? vm : 0u, mm);
+                    const uint32_t v2 = vote_bits(hu, rw[g], rw[g + 1], s2 + 16 * g, has2 ? vm : 0u, mm);
+                    const uint32_t v3 = vote_bits(hu, rw[g], rw[g + 1], s3 + 16 * g, has3 ? vm : 0u, mm);
                     if (v1) last1 = 16 * g + ((31 - __clz((int)v1)) >> 1);
                     if (v2) last2 = 16 * g + ((31 - __clz((int)v2)) >> 1);
                     if (v3) last3 = 16 * g + ((31 - __clz((int)v3)) >> 1);
                 }
             }
-            last1 = quad_max(last1); last2 = quad_max(last2); last3 = quad_max(last3);
             if (tie) {
                 int best = 0x7fffffff;
                 if (has3 && n3 == top) { best = last3; winner = c3; }
@@ -876,40 +897,65 @@ __global__ __launch_bounds__(256) void k_vote5(const uint32_t* __restrict__ hap2
                 if (has1 && n1 == top && last1 < best) { best = last1; winner = c1; }
             }
         }
-        if (mine && part == 0 && !undecided) anchor[rec.pair] = winner - 8 > 0 ? winner - 8 : 0;   // calign.pyx:67
+        if (active && !undecided) anchor[rec.pair] = winner - 8 > 0 ? winner - 8 : 0;   // calign.pyx:67
 
-        // ---- steps 3 and 4: the wavefront takes the reads the candidates do not decide, one at a time ----
-        unsigned long long todo = __ballot(undecided && part == 0);
+        // ---- the wavefront takes the reads the candidates do not decide, one at a time ----
+        unsigned long long todo = __ballot(undecided);
         while (todo) {
-            const int j = __ffsll((long long)todo) - 1;
+            const int jl = __ffsll((long long)todo) - 1;
             todo &= todo - 1;
-            const int pair = __builtin_amdgcn_readlane(rec.pair, j);
-            const int nvj = __builtin_amdgcn_readlane(nv, j);
+            const int pair = __builtin_amdgcn_readlane(rec.pair, jl);
+            const int nvj = __builtin_amdgcn_readlane(nv, jl);
+            const int slj = __builtin_amdgcn_readlane(slot_i, jl);
+            const int nkj = __builtin_amdgcn_readlane(nk, jl);
+            const int hmj = __builtin_amdgcn_readlane(hm, jl);
             const int ngj = (nvj + 15) >> 4;
-            if ((lane >> 2) == (j >> 2)) {                                     // its words are in its quad's registers
+            if (lane == jl) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (part + 4 * k < ngj) { rrow[part + 4 * k] = Qc.g[k].x; rrow[part + 4 * k + 1] = Qc.g[k].y; }
+                for (int k = 0; k < 17; ++k) rrow[k] = rw[k];
             }
             __builtin_amdgcn_wave_barrier();
+            const uint2* huj = reinterpret_cast<const uint2*>(lds + slj * slot_words);
+            const uint16_t* ctj = reinterpret_cast<const uint16_t*>(lds + slj * slot_words + 2 * row_cap);
+            const uint32_t* ub = hapUbits + (size_t)hmj * (kHashSize / 32);
             // exact count and last vote of one position; key = count << 16 | (0xffff - last vote): the largest key is
             // the largest count and, among equal counts, the earliest last vote
             auto key_of = [&](int cc) -> uint32_t {
                 int n = 0, last = -1;
                 for (int g = 0; g < ngj; ++g) {
-                    const uint32_t v = vote_bits(hu, rrow[g], rrow[g + 1], base + cc + 16 * g, group_mask(nvj, g));
+                    uint32_t mm;
+                    const uint32_t v = vote_bits(huj, rrow[g], rrow[g + 1], base + cc + 16 * g, group_mask(nvj, g), mm);
                     n += __popc(v);
                     if (v) last = 16 * g + ((31 - __clz((int)v)) >> 1);
                 }
                 return n > 0 ? ((uint32_t)n << 16) | (uint32_t)(0xffff - last) : 0u;
             };
+            // first the other bound on every other position's count: only 7-mers owned by a unique start vote at all
+            {
+                int tot = 0;
+                for (int i = lane; i < nvj; i += 64) {
+                    const uint32_t key = hash7_lds(rrow, i);
+                    tot += (int)((ub[key >> 5] >> (key & 31u)) & 1u);
+                }
+                tot = wave_sum(tot);
+                const int topj = __builtin_amdgcn_readlane(top, jl), sumj = __builtin_amdgcn_readlane(n1 + n2 + n3, jl);
+                const int holders = (int)(has1 && n1 == top) + (int)(has2 && n2 == top) + (int)(has3 && n3 == top);
+                const int holdj = __builtin_amdgcn_readlane(holders, jl);
+                const int winj = __builtin_amdgcn_readlane((has1 && n1 == top) ? c1 : (has2 && n2 == top) ? c2 : c3, jl);
+                if (tot == 0 || (topj > tot - sumj && holdj == 1)) {           // nothing votes: position 0 (calign.pyx:137)
+                    const int w0 = tot == 0 ? 0 : winj;
+                    if (lane == 0) anchor[pair] = w0 - 8 > 0 ? w0 - 8 : 0;
+                    __builtin_amdgcn_wave_barrier();
+                    continue;
+                }
+            }
             uint32_t best_key = 0;
             int best_c = 0, lost = 0;
-            for (int i = lane; i < nvj; i += 64) {                             // step 3: the positions this lane's offsets name
+            for (int i = lane; i < nvj; i += 64) {                             // a: the positions this lane's offsets name
                 const uint32_t key = hash7_lds(rrow, i);
-                if ((ubits[key >> 5] >> (key & 31u)) & 1u) {
+                if ((ub[key >> 5] >> (key & 31u)) & 1u) {
                     int jpos;
-                    if (cand_lookup(hu, ctab, pad, nk, key, jpos)) {
+                    if (cand_lookup(huj, ctj, pad, nkj, key, jpos)) {
                         const uint32_t k2 = key_of(jpos - i);
                         if (k2 > best_key) { best_key = k2; best_c = jpos - i; }
                     } else {
@@ -920,10 +966,10 @@ __global__ __launch_bounds__(256) void k_vote5(const uint32_t* __restrict__ hap2
             lost = wave_sum(lost);
             uint32_t wmax = (uint32_t)wave_max_nonneg((int)best_key);          // counts are below 2^15
             const bool full = (int)(wmax >> 16) <= lost && !(wmax == 0 && lost == 0);
-            if (full) {                                                        // step 4: positions -(nvj - 1) .. nk - 1, all of them
+            if (full) {                                                        // b: positions -(nvj - 1) .. nk - 1, all of them
                 best_key = 0;
                 best_c = 0;
-                for (int cc = -(nvj - 1) + lane; cc < nk; cc += 64) {
+                for (int cc = -(nvj - 1) + lane; cc < nkj; cc += 64) {
                     const uint32_t k2 = key_of(cc);
                     if (k2 > best_key) { best_key = k2; best_c = cc; }
                 }
@@ -937,11 +983,6 @@ __global__ __launch_bounds__(256) void k_vote5(const uint32_t* __restrict__ hap2
             }
             __builtin_amdgcn_wave_barrier();
         }
-        rec = rec_next;
-        rec_next = rec_after;
-        vote5_fetch(Q_next, read2 + rec_next.r2off, part, votes_of(rec_next), (votes_of(rec_next) + 15) >> 4);
-    }
-    __syncthreads();                                 // the next haplotype's rows overwrite these
     }
 }
 

@@ -107,7 +107,6 @@ struct pg_ctx {
     // kernel-choice overrides of pg_set_option (tests and measurements); 0 / -1 = the library decides
     int vote_waves = 0;                  // "vote_waves": wavefronts per workgroup of the vote kernel
     int vote_kernel = -1;                // "vote_kernel": 0 position table in LDS (k_vote4), 1 bit-parallel counts (k_vote5)
-    int vote_grid = 0;                   // "vote_grid": workgroups of k_vote5 (0: what the chip holds at once)
     int lds_pad = 0;                     // "align_lds_pad": extra LDS per workgroup of the DP kernel, lowers its occupancy
     int gl_kernel = -1;                  // "gl_kernel": 0 cell, 1 tile
     int em_kernel = -1;                  // "em_kernel": 0 small, 1 big, 2 multi
@@ -127,6 +126,7 @@ struct pg_ctx {
     DevBuf<uint16_t> d_hapx;
     DevBuf<uint32_t> d_hap2;            // 2-bit packed bases
     DevBuf<uint32_t> d_hapU;            // indel-bearing haplotypes: starts that own a unique 7-mer, same layout
+    DevBuf<uint32_t> d_hapUbits;        // ... and one bit per 7-mer value: owned by a unique start (512 words each)
     DevBuf<int64_t> d_hap2off;
     DevBuf<int64_t> d_hap_soff, d_hap_doff;
     DevBuf<int32_t> d_hap_len, d_hap_start, d_hap_varlen;
@@ -326,17 +326,19 @@ int enqueue_align(pg_ctx* c, const pg::PairWork& W, const int32_t* pair_hap, con
     // reads of up to 263 bases (sixteen 16-base groups) take the table-free kernel
     const bool bits = c->vote_kernel >= 0 ? (c->vote_kernel == 1 && c->max_rlen <= 263) : c->max_rlen <= 263;
     if (c->n_vote_haps > 0 && bits) {
-        PG_HIP(c, hipMemsetAsync(W.status + pg::ST_N_NAMED, 0, 10 * sizeof(int32_t), c->stream));   // counted per launch
+        PG_HIP(c, hipMemsetAsync(W.status + pg::ST_N_NAMED, 0, 2 * sizeof(int32_t), c->stream));   // counted per launch
         const int pad = (c->max_rlen + 15) / 16 + 3;
         const int row_cap = (c->max_hap_len + 15) / 16 + 2 + 2 * pad;
-        int n_wav = c->vote_waves > 0 ? std::min(c->vote_waves, 4) : (np / std::max(1, c->n_haps) > 48 ? 4 : 2);
-        const size_t lds = (size_t)row_cap * 8 + (size_t)pg::kCandSlots * 2 + (size_t)pg::kHashSize / 8 + (size_t)n_wav * 20 * 4;
+        // one lane per pair: a workgroup takes the next 64 * n_wav vote records, whatever haplotypes they are on
+        const int n_wav = c->vote_waves > 0 ? std::min(c->vote_waves, 4) : 2;
+        const size_t lds = ((size_t)pg::kVoteSlots * (2 * (size_t)row_cap + pg::kCandSlots / 2) + (size_t)n_wav * 20) * 4;
+        if (lds > 160 * 1024)
+            return fail(c, PG_ERR_UNSUPPORTED, "anchoring rows for haplotype length %d need %zu bytes of LDS", c->max_hap_len, lds);
         PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_vote5), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        // one workgroup per haplotype measured best (wgs-like stream: 0.107 ms; 2048 workgroups looping over the
-        // haplotypes 0.115, 1024: 0.173); "vote_grid" sets another number
-        const int grid = std::min(c->n_vote_haps, c->vote_grid > 0 ? c->vote_grid : c->n_vote_haps);
-        hipLaunchKernelGGL(pg::k_vote5, dim3(grid), dim3(64 * n_wav), lds, c->stream, c->d_hap2.p, c->d_hapU.p,
-                           c->d_read2.p, c->d_vh.p, W.hap_cnt, W.recs, W.status, W.anchor_in, pad, row_cap, c->n_vote_haps);
+        const int64_t grid = (np + 64 * n_wav - 1) / (64 * n_wav);          // records <= pairs; workgroups past the last record return
+        hipLaunchKernelGGL(pg::k_vote5, dim3((unsigned)grid), dim3(64 * n_wav), lds, c->stream, c->d_hap2.p, c->d_hapU.p,
+                           c->d_hapUbits.p, c->d_read2.p, c->d_vh.p, W.hap_cnt, W.recs, W.status, W.anchor_in, pad, row_cap,
+                           c->n_vote_haps);
         PG_HIP(c, hipGetLastError());
     } else if (c->n_vote_haps > 0) {
         int cnt_stride = c->max_hap_len + c->max_rlen + 8;
@@ -458,7 +460,7 @@ int pg_ctx_destroy(pg_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     c->d_tab1.release(); c->d_codes.release(); c->d_hapx.release();
-    c->d_readx.release(); c->d_read_xoff.release(); c->d_hap2.release(); c->d_hapU.release(); c->d_hap2off.release();
+    c->d_readx.release(); c->d_read_xoff.release(); c->d_hap2.release(); c->d_hapU.release(); c->d_hapUbits.release(); c->d_hap2off.release();
     c->d_read2.release(); c->d_read2off.release();
     c->d_exp_score.release(); c->d_exp_mapq.release();
     c->d_hap_raw.release();
@@ -539,8 +541,6 @@ int pg_set_option(pg_ctx* c, const char* name, const char* value) {
         c->em_step_waves = dflt ? 0 : std::max(1, std::min(16, std::atoi(value)));
     } else if (n == "vote_waves") {
         c->vote_waves = dflt ? 0 : std::max(1, std::min(4, std::atoi(value)));
-    } else if (n == "vote_grid") {
-        c->vote_grid = dflt ? 0 : std::max(1, std::atoi(value));
     } else if (n == "vote_kernel") {
         if (dflt) c->vote_kernel = -1; else if (v == "table") c->vote_kernel = 0; else if (v == "bits") c->vote_kernel = 1;
         else return fail(c, PG_ERR_INVALID, "vote_kernel: table, bits or default");
@@ -624,7 +624,9 @@ int pg_haps_upload(pg_ctx* c, int n, const char* seq, const int64_t* off,
         // which of their starts own a unique 7-mer (the reference's table entries > 0, calign.pyx:114-121): a row per
         // haplotype beside its packed bases, made once here and read by every launch's anchoring kernel
         PG_HIP(c, c->d_hapU.reserve((size_t)off2[n] + 16));
-        hipLaunchKernelGGL(pg::k_hap_unique, dim3((unsigned)vh.size()), dim3(256), 0, c->stream, c->d_hap2.p, c->d_vh.p, c->d_hapU.p);
+        PG_HIP(c, c->d_hapUbits.reserve(vh.size() * (size_t)(pg::kHashSize / 32)));
+        hipLaunchKernelGGL(pg::k_hap_unique, dim3((unsigned)vh.size()), dim3(256), 0, c->stream, c->d_hap2.p, c->d_vh.p, c->d_hapU.p,
+                           c->d_hapUbits.p);
         PG_HIP(c, hipGetLastError());
     }
     int32_t bad = 0;
@@ -864,9 +866,6 @@ int pg_anchor_stats(pg_ctx* c, int64_t* counts) {
     counts[0] = c->h_status[pg::ST_N_VOTE];
     counts[1] = c->h_status[pg::ST_N_NAMED];
     counts[2] = c->h_status[pg::ST_N_FULL];
-#ifdef PG_VOTE_DEBUG
-    fprintf(stderr, "vote debug: again %d, no c1 %d, only c1 %d, sum n1 %d, sum cover %d, sum nv %d, waves in step 2: %d\n", c->h_status[5], c->h_status[6], c->h_status[7], c->h_status[8], c->h_status[9], c->h_status[10], c->h_status[11]);
-#endif
     return PG_OK;
 }
 
