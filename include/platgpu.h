@@ -365,7 +365,7 @@ int pg_valu_vop2_rate(pg_ctx *ctx, double *lane_instructions_per_second);
  * Replaces, for the stretch of a BAM file a region fetch reads, what the
  * reference gets from its vendored samtools: bgzf_read_block / inflate_block
  * (platypus/c/samtools/bgzf.c), reached through bam_read1 from
- * platypus/samtoolsWrapper.pyx (Samfile.fetch, IteratorRow).  One lane
+ * platypus/samtoolsWrapper.pyx (Samfile.fetch, IteratorRow).  One wavefront
  * inflates one BGZF block; the host finds the block boundaries only.
  *
  * An inflater is independent of any pg_ctx (own stream, device buffers and one
@@ -377,7 +377,8 @@ int pg_inflater_create(int device_ordinal, pg_inflater **out);
 int pg_inflater_destroy(pg_inflater *h);
 /* message of the last failed call on h (of the last failed create for NULL) */
 const char *pg_inflater_error(const pg_inflater *h);
-/* BGZF blocks per wavefront, 8 (default), 16 or 32: measurements */
+/* 1 (default): one wavefront inflates one BGZF block; 8, 16 or 32: one lane per block, that many blocks per
+ * wavefront (the first version of the kernel, kept for comparison) */
 int pg_inflater_set_lanes(pg_inflater *h, int lanes);
 /* device time of the last call's kernel, milliseconds */
 int pg_inflater_last_ms(pg_inflater *h, float *ms);

@@ -1320,7 +1320,7 @@ struct pg_inflater {
     std::vector<pg::InflBlock> blocks;
     int32_t* h_status = nullptr;                  // page-locked as well: a copy into pageable memory would make the call spin
     size_t h_status_cap = 0;
-    int lanes = 8;                                // BGZF blocks per wavefront (8, 16 or 32; 3272 bytes of LDS each)
+    int lanes = 1;                                // 1: one wavefront per BGZF block; 8, 16, 32: one lane per block, that many per wavefront
     float last_ms = 0;
     hipEvent_t t0 = nullptr, t1 = nullptr;
     std::string err;
@@ -1456,7 +1456,7 @@ int pg_inflater_input(pg_inflater* h, size_t bytes, void** buf) {
 }
 
 int pg_inflater_set_lanes(pg_inflater* h, int lanes) {
-    if (!h || (lanes != 8 && lanes != 16 && lanes != 32)) return PG_ERR_INVALID;
+    if (!h || (lanes != 1 && lanes != 8 && lanes != 16 && lanes != 32)) return PG_ERR_INVALID;
     h->lanes = lanes;
     return PG_OK;
 }
@@ -1506,7 +1506,7 @@ int pg_bgzf_inflate(pg_inflater* h, const void* raw_, size_t n_raw, const void* 
     h->last_ms = 0;
     const int nb = (int)h->blocks.size();
     if (nb == 0 || total == 0) return PG_OK;
-    PG_IHIP(h, h->d_raw.reserve(eaten + 64));
+    PG_IHIP(h, h->d_raw.reserve(eaten + 2048));    // the kernels read whole words and, ahead of the decoder, up to 540 bytes past a stream
     PG_IHIP(h, h->d_out.reserve(total + 64));
     PG_IHIP(h, h->d_blocks.reserve(nb));
     PG_IHIP(h, h->d_status.reserve(nb));
@@ -1520,7 +1520,12 @@ int pg_bgzf_inflate(pg_inflater* h, const void* raw_, size_t n_raw, const void* 
     PG_IHIP(h, hipMemcpyAsync(h->d_raw.p, raw, eaten, hipMemcpyHostToDevice, h->stream));
     PG_IHIP(h, hipMemcpyAsync(h->d_blocks.p, h->blocks.data(), (size_t)nb * sizeof(pg::InflBlock), hipMemcpyHostToDevice, h->stream));
     PG_IHIP(h, hipEventRecord(h->t0, h->stream));
-    if (h->lanes == 8) PG_IHIP(h, launch_inflate<8>(h, nb));
+    if (h->lanes == 1) {
+        PG_IHIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_bgzf_inflate_wave), hipFuncAttributeMaxDynamicSharedMemorySize, pg::IW_LDS));
+        hipLaunchKernelGGL(pg::k_bgzf_inflate_wave, dim3(nb), dim3(64), pg::IW_LDS, h->stream, h->d_raw.p, h->d_blocks.p, nb, h->d_out.p, h->d_status.p);
+        PG_IHIP(h, hipGetLastError());
+    }
+    else if (h->lanes == 8) PG_IHIP(h, launch_inflate<8>(h, nb));
     else if (h->lanes == 16) PG_IHIP(h, launch_inflate<16>(h, nb));
     else PG_IHIP(h, launch_inflate<32>(h, nb));
     PG_IHIP(h, hipEventRecord(h->t1, h->stream));
@@ -1532,7 +1537,7 @@ int pg_bgzf_inflate(pg_inflater* h, const void* raw_, size_t n_raw, const void* 
     {   // a lane needs about 0.4 us per byte of its block: sleep through most of the largest block's time, then poll
         uint32_t longest = 0;
         for (const pg::InflBlock& b : h->blocks) longest = std::max(longest, b.out_len);
-        const double first_us = 0.3 * (double)longest;
+        const double first_us = (h->lanes == 1 ? 0.02 : 0.3) * (double)longest;
         if (first_us > 500.0) usleep((useconds_t)first_us);
     }
     for (;;) {

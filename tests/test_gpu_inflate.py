@@ -42,7 +42,7 @@ def _payloads(rng, n):
     return out
 
 
-@pytest.mark.parametrize("lanes", [8, 16, 32])
+@pytest.mark.parametrize("lanes", [1, 8, 16, 32])
 def test_inflate_equals_zlib(lanes):
     from platypus_amd import native
     rng = np.random.default_rng(100 + lanes)

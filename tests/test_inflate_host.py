@@ -79,3 +79,92 @@ def test_damaged_streams_stay_inside_their_buffers(infl):
     assert rc in (6, 8)
     rc, _ = _run(infl, body, len(data) + 1, 20)
     assert rc == 8
+
+
+class _Bits(object):
+    def __init__(self):
+        self.acc, self.n, self.out = 0, 0, bytearray()
+
+    def put(self, value, nbits):                                   # low bit first (RFC 1951, 3.1.1)
+        self.acc |= value << self.n
+        self.n += nbits
+        while self.n >= 8:
+            self.out.append(self.acc & 255)
+            self.acc >>= 8
+            self.n -= 8
+
+    def code(self, code, nbits):                                   # Huffman codes go out high bit first
+        for k in range(nbits - 1, -1, -1):
+            self.put((code >> k) & 1, 1)
+
+    def done(self):
+        if self.n:
+            self.out.append(self.acc & 255)
+        return bytes(self.out)
+
+
+def _canonical(lengths):
+    """symbol -> (code, length) of the canonical code with these lengths (RFC 1951, 3.2.2)"""
+    codes, code = {}, 0
+    for l in range(1, 16):
+        for s, ls in enumerate(lengths):
+            if ls == l:
+                codes[s] = (code, l)
+                code += 1
+        code <<= 1
+    return codes
+
+
+def _dynamic_block(lit, dst, clc=None, body=(256,)):
+    """one final dynamic block whose literal/length and distance code lengths are `lit`, `dst`, written one by one
+    with a code length code of lengths `clc` (default: a complete one: 13 symbols of 4 bits, 6 of 5); `body`:
+    literal/length symbols to emit"""
+    if clc is None:
+        clc = [4] * 13 + [5] * 6
+    w = _Bits()
+    w.put(1, 1)
+    w.put(2, 2)
+    w.put(len(lit) - 257, 5)
+    w.put(len(dst) - 1, 5)
+    w.put(19 - 4, 4)
+    for s in (16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15):
+        w.put(clc[s], 3)
+    cc = _canonical(clc)
+    for l in list(lit) + list(dst):
+        if l in cc:
+            w.code(*cc[l])
+    lc = _canonical(lit)
+    for s in body:
+        if s in lc:
+            w.code(*lc[s])
+    return w.done() + bytes(4)
+
+
+@pytest.mark.parametrize("name,lit,dst,clc", [
+    ("complete sets", {0: 1, 256: 1}, {0: 1, 1: 1}, None),
+    ("one distance code of one bit", {0: 1, 256: 1}, {0: 1}, None),
+    ("no distance code at all", {0: 1, 256: 1}, {}, None),
+    ("one literal/length code of one bit", {256: 1}, {0: 1}, None),
+    ("incomplete literal/length set", {0: 2, 1: 2, 256: 2}, {0: 1, 1: 1}, None),
+    ("incomplete distance set of two codes", {0: 1, 256: 1}, {0: 2, 1: 2}, None),
+    ("one distance code of two bits", {0: 1, 256: 1}, {0: 2}, None),
+    ("over-subscribed literal/length set", {0: 1, 1: 1, 256: 1}, {0: 1, 1: 1}, None),
+    ("over-subscribed distance set", {0: 1, 256: 1}, {0: 1, 1: 1, 2: 1}, None),
+    ("incomplete code length code", {0: 1, 256: 1}, {0: 1, 1: 1}, [4] * 12 + [0] + [5] * 6),
+    ("no end-of-block code", {0: 1, 1: 1}, {0: 1, 1: 1}, None),
+])
+def test_sets_of_code_lengths_are_accepted_where_zlib_accepts_them(infl, name, lit, dst, clc):
+    """zlib's inflate_table (what the reference's inflate_block runs) refuses over-subscribed sets, and incomplete
+    ones unless they are a single code of one bit outside the code length code; so does this decoder"""
+    lit_l = [lit.get(s, 0) for s in range(257)]
+    dst_l = [dst.get(s, 0) for s in range(max(1, max(dst) + 1 if dst else 1))]
+    body = _dynamic_block(lit_l, dst_l, clc)
+    try:
+        want = zlib.decompressobj(-15).decompress(body)
+        ok = True
+    except zlib.error:
+        want, ok = None, False
+    rc, out = _run(infl, body, 0, 20)
+    assert (rc == 0) == ok, (name, rc, ok)
+    if ok:
+        assert want == b""
