@@ -356,25 +356,35 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const unsigned char* __rest
 
 // ---------------------------------------------------------------------------------------------------------
 // One wavefront per BGZF block.
-// LDS: tables (one lane's layout) | last 32 KiB of output (ring) | 2 KiB of compressed input (ring of words) |
-// tokens of a batch.
+//
+// What is serial in a deflate stream is finding where the next token starts.  The wavefront finds 64 starts' worth at
+// once: lane i decodes the whole token that WOULD start at bit i of the next 64 bits -- a literal, or a length code,
+// its extra bits, the distance code and its extra bits, through the direct tables (all lanes use the same tables) --
+// and the true starts are the chain 0 -> 0 + bits[0] -> ... followed through the lanes' answers: a register read per
+// token instead of two table look-ups and their waits.  The tokens of the chain whose sources lie before the pass's
+// own output do not depend on each other: their lanes write them side by side, from a ring of the last 32 KiB of
+// output in LDS (the deflate window: no match ever waits for global memory, which is what bound one lane per block
+// at 0.4 us per byte) into the ring and into global memory at once.  A token that ends the chain -- a match that
+// overlaps the pass's output or its own, a long one, the end-of-block code, a code beyond the direct tables -- is
+// decoded the ordinary way and copied by the whole wavefront, 64 bytes per step.
+// LDS: tables (one lane's layout) | output ring | 2 KiB of compressed input (ring of words).  Four workgroups of
+// one wavefront fit a CU: one per SIMD.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int IW_OUT = 32768;                    // output ring: the deflate window
 constexpr int IW_IN_WORDS = 512;                 // input ring, 32-bit words
-constexpr int IW_TOK = 64;                       // tokens per batch
-constexpr int IW_LDS = IT_U16 * 2 + IW_OUT + IW_IN_WORDS * 4 + IW_TOK * 4 + IW_TOK * 2 + 64;
+constexpr int IW_LDS = IT_U16 * 2 + IW_OUT + IW_IN_WORDS * 4 + 64;
 
-struct InflRingBits {                            // lane 0's bit reader over the input ring
+struct InflRingBits {                            // lane 0's bit reader over the input ring (block headers)
     const uint32_t* ring;
     uint32_t wi;                                 // next word to take, counted from the aligned start of the stream
     uint64_t bb;
     int bc;
-    __device__ void start(uint32_t byte_off) {   // byte_off from the aligned start
-        wi = byte_off >> 2;
-        const int skip = (int)(byte_off & 3);
-        bb = (uint64_t)ring[wi & (IW_IN_WORDS - 1)] >> (8 * skip);
+    __device__ void start_bits(uint32_t bitpos) {
+        wi = bitpos >> 5;
+        const int skip = (int)(bitpos & 31u);
+        bb = (uint64_t)ring[wi & (IW_IN_WORDS - 1)] >> skip;
         ++wi;
-        bc = 32 - 8 * skip;
+        bc = 32 - skip;
     }
     __device__ void refill() {
         if (bc < 32) {
@@ -389,7 +399,12 @@ struct InflRingBits {                            // lane 0's bit reader over the
         bc -= n;
         return v;
     }
-    __device__ uint32_t byte_pos() const { return 4 * wi - (uint32_t)(bc >> 3); }   // first byte not consumed (bc multiple of 8)
+    __device__ uint32_t bit_pos() const { return 32u * wi - (uint32_t)bc; }   // first bit not consumed
+};
+
+struct InflPeek {                                // 64 bits of the stream from a bit position on (every lane the same)
+    uint64_t bb;
+    int bc;
 };
 
 __global__ __launch_bounds__(64) void k_bgzf_inflate_wave(const unsigned char* __restrict__ raw, const InflBlock* __restrict__ blocks,
@@ -404,42 +419,49 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate_wave(const unsigned char* _
     T.t = reinterpret_cast<unsigned short*>(infl_lds);
     unsigned char* oring = infl_lds + IT_U16 * 2;
     uint32_t* iring = reinterpret_cast<uint32_t*>(oring + IW_OUT);
-    uint32_t* tok_val = iring + IW_IN_WORDS;                                  // literal: 0x80000000 | byte; match: len << 16 | dist
-    unsigned short* tok_pos = reinterpret_cast<unsigned short*>(tok_val + IW_TOK);   // where it starts in the block's output
     unsigned char* const gout = out + K.out_off;
     const uint32_t* const words = reinterpret_cast<const uint32_t*>(raw) + (K.in_off >> 2);   // raw is 4-byte aligned and padded
     const uint32_t lead = K.in_off & 3u;                                      // the stream starts `lead` bytes into words[0]
     const uint32_t n_words = (lead + K.in_len + 3) >> 2;                     // words that hold the stream
-    uint32_t loaded = 0;                                                      // words in the ring so far (whole wavefront knows)
+    const uint32_t end_bit = 8u * (lead + K.in_len);
+    uint32_t loaded = 0;                                                      // words in the ring so far
 
-    // keeps the ring full: 128 words at a time while that many are free (consumed: words lane 0 has taken)
+    // keeps the ring full: 128 words at a time while that many are free (consumed: words nobody needs any more)
     auto feed = [&](uint32_t consumed) {
         while (loaded < n_words + 8 && loaded + 128 <= consumed + IW_IN_WORDS) {
             const uint32_t w = loaded + 2 * lane;
-            iring[w & (IW_IN_WORDS - 1)] = words[w];                          // (up to 8 words past the stream: padding)
+            iring[w & (IW_IN_WORDS - 1)] = words[w];                          // (up to 135 words past the stream: padding)
             iring[(w + 1) & (IW_IN_WORDS - 1)] = words[w + 1];
             loaded += 128;
         }
         __builtin_amdgcn_wave_barrier();
     };
     feed(0);
+    auto peek64 = [&](uint32_t bitpos) -> InflPeek {
+        const uint32_t w = bitpos >> 5, sh = bitpos & 31u;
+        const uint32_t a = iring[w & (IW_IN_WORDS - 1)], c = iring[(w + 1) & (IW_IN_WORDS - 1)], d = iring[(w + 2) & (IW_IN_WORDS - 1)];
+        InflPeek P;
+        P.bb = ((uint64_t)__builtin_amdgcn_alignbit(d, c, sh) << 32) | __builtin_amdgcn_alignbit(c, a, sh);
+        P.bc = 64;
+        return P;
+    };
 
-    // lane 0's state
-    InflRingBits B;
-    B.ring = iring;
-    B.bb = 0; B.bc = 0; B.wi = 0;
-    if (lane == 0) B.start(lead);
+    uint32_t bitpos = 8u * lead;                                              // everything below is the same in every lane
     uint32_t op = 0;                                                          // bytes of output so far
     int n_lit = 0, n_dst = 0;
     int err = INF_OK;
     bool in_block = false, last = false, done = false;
 
-    for (int guard = 0; guard < (1 << 20) && !done; ++guard) {                // every pass consumes input or ends
-        // ---- lane 0: a block header, or up to IW_TOK tokens ----
-        int n_tok = 0;
-        uint32_t stored_at = 0, stored_len = 0;                               // a stored block for the wavefront to copy
-        if (lane == 0) {
-            if (!in_block) {
+    for (int guard = 0; guard < (1 << 22) && !done && !err; ++guard) {        // every pass consumes input or ends
+        if (bitpos > end_bit + 64u) { err = INF_INPUT_OVERRUN; break; }
+        if (!in_block) {
+            // ---- a block header: lane 0 reads it and builds the tables ----
+            uint32_t stored_at = 0, stored_len = 0;
+            int e0 = INF_OK;
+            if (lane == 0) {
+                InflRingBits B;
+                B.ring = iring;
+                B.start_bits(bitpos);
                 B.refill();
                 last = B.take(1) != 0;
                 const uint32_t type = B.take(2);
@@ -449,17 +471,14 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate_wave(const unsigned char* _
                     const uint32_t len = B.take(16);
                     B.refill();
                     const uint32_t nlen = B.take(16);
-                    if ((len ^ nlen) != 0xffffu) err = INF_BAD_STORED;
-                    stored_at = B.byte_pos();
+                    if ((len ^ nlen) != 0xffffu) e0 = INF_BAD_STORED;
+                    stored_at = B.bit_pos() >> 3;                             // byte-aligned here
                     stored_len = len;
-                    if (!err && stored_at + len > lead + K.in_len) err = INF_INPUT_OVERRUN;
-                    if (!err && op + len > K.out_len) err = INF_OUTPUT_OVERRUN;
-                    if (!err) {
-                        stored_len |= 0x80000000u;                             // "copy this" (even an empty one: the reader moves on)
-                        if (last) done = true;
-                    }
+                    if (!e0 && stored_at + len > lead + K.in_len) e0 = INF_INPUT_OVERRUN;
+                    if (!e0 && op + len > K.out_len) e0 = INF_OUTPUT_OVERRUN;
+                    if (!e0) stored_len |= 0x80000000u;                        // "copy this" (even an empty one: the reader moves on)
                 } else if (type == 3) {
-                    err = INF_BAD_BLOCK_TYPE;
+                    e0 = INF_BAD_BLOCK_TYPE;
                 } else {
                     int dst_at = 0;
                     if (type == 1) {                                          // fixed codes (RFC 1951, 3.2.6)
@@ -471,22 +490,22 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate_wave(const unsigned char* _
                         n_lit = (int)B.take(5) + 257;
                         n_dst = (int)B.take(5) + 1;
                         const int n_clc = (int)B.take(4) + 4;
-                        if (n_lit > 286 || n_dst > 30) err = INF_BAD_LENGTHS;
+                        if (n_lit > 286 || n_dst > 30) e0 = INF_BAD_LENGTHS;
                         for (int s = 0; s < 19; ++s) T.u8(IT_LENS, s) = 0;
-                        for (int i = 0; i < n_clc && !err; ++i) {
+                        for (int i = 0; i < n_clc && !e0; ++i) {
                             B.refill();
                             // order of the code length code's lengths (3.2.7): 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
                             const int s = (int)((i < 12 ? 0x22caa324e804a30ull >> (5 * i) : 0x3c2e1346cull >> (5 * (i - 12))) & 31);
                             T.u8(IT_LENS, s) = (unsigned char)B.take(3);
                         }
-                        if (!err && !infl_build(T, IT_LENS, 0, 19, IT_CLC_SYM, IT_CLC_THR, IT_CLC_BASE, IK_CODES)) err = INF_BAD_LENGTHS;
+                        if (!e0 && !infl_build(T, IT_LENS, 0, 19, IT_CLC_SYM, IT_CLC_THR, IT_CLC_BASE, IK_CODES)) e0 = INF_BAD_LENGTHS;
                         int at = 0, prev = 0;
                         const int total = n_lit + n_dst;
-                        while (!err && at < total) {                          // (at most 316 lengths of at most 14 bits: the ring holds them)
+                        while (!e0 && at < total) {                           // (at most 316 lengths of at most 14 bits: the ring holds them)
                             B.refill();
-                            if (B.wi > n_words + 4) { err = INF_INPUT_OVERRUN; break; }
+                            if (B.wi > n_words + 4) { e0 = INF_INPUT_OVERRUN; break; }
                             const int s = infl_decode(T, B, IT_CLC_SYM, IT_CLC_THR, IT_CLC_BASE, 19);
-                            if (s < 0) { err = INF_BAD_CODE; break; }
+                            if (s < 0) { e0 = INF_BAD_CODE; break; }
                             if (s < 16) {
                                 T.u8(IT_LENS, at) = (unsigned char)s;
                                 prev = s;
@@ -494,7 +513,7 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate_wave(const unsigned char* _
                             } else {
                                 int rep, val = 0;
                                 if (s == 16) {
-                                    if (at == 0) { err = INF_BAD_LENGTHS; break; }
+                                    if (at == 0) { e0 = INF_BAD_LENGTHS; break; }
                                     val = prev;
                                     rep = 3 + (int)B.take(2);
                                 } else if (s == 17) {
@@ -502,160 +521,210 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate_wave(const unsigned char* _
                                 } else {
                                     rep = 11 + (int)B.take(7);
                                 }
-                                if (at + rep > total) { err = INF_BAD_LENGTHS; break; }
+                                if (at + rep > total) { e0 = INF_BAD_LENGTHS; break; }
                                 for (int k = 0; k < rep; ++k) T.u8(IT_LENS, at + k) = (unsigned char)val;
                                 at += rep;
                                 prev = val;
                             }
                         }
-                        if (!err && T.u8(IT_LENS, 256) == 0) err = INF_BAD_LENGTHS;       // no end-of-block code
+                        if (!e0 && T.u8(IT_LENS, 256) == 0) e0 = INF_BAD_LENGTHS;        // no end-of-block code
                         dst_at = n_lit;
                     }
-                    if (!err && !infl_build(T, IT_LENS, 0, n_lit, IT_LIT_SYM, IT_LIT_THR, IT_LIT_BASE, IK_LENS, IT_FAST, IT_FAST_BITS)) err = INF_BAD_LENGTHS;
-                    if (!err && !infl_build(T, IT_LENS, dst_at, n_dst, IT_DST_SYM, IT_DST_THR, IT_DST_BASE, IK_DISTS, IT_DFAST, IT_DFAST_BITS)) err = INF_BAD_LENGTHS;
+                    if (!e0 && !infl_build(T, IT_LENS, 0, n_lit, IT_LIT_SYM, IT_LIT_THR, IT_LIT_BASE, IK_LENS, IT_FAST, IT_FAST_BITS)) e0 = INF_BAD_LENGTHS;
+                    if (!e0 && !infl_build(T, IT_LENS, dst_at, n_dst, IT_DST_SYM, IT_DST_THR, IT_DST_BASE, IK_DISTS, IT_DFAST, IT_DFAST_BITS)) e0 = INF_BAD_LENGTHS;
                     in_block = true;
                 }
-            } else {
-                // tokens: while the batch has room and the ring holds the next one whole (at most 48 bits)
-                if (B.wi + 3 > loaded && loaded >= n_words + 8) err = INF_INPUT_OVERRUN;   // nothing more will come
-                while (!err && n_tok < IW_TOK && B.wi + 3 <= loaded) {
-                    B.refill();
-                    int s;
-                    const uint32_t quick = T.u16(IT_FAST, (int)((uint32_t)B.bb & ((1u << IT_FAST_BITS) - 1)));
-                    if (quick) {                                              // a code of up to ten bits: one look-up
-                        s = (int)(quick & 511u);
-                        B.bb >>= quick >> 9;
-                        B.bc -= (int)(quick >> 9);
-                    } else {
-                        s = infl_decode(T, B, IT_LIT_SYM, IT_LIT_THR, IT_LIT_BASE, n_lit);
-                        if (s < 0) { err = INF_BAD_CODE; break; }
-                    }
-                    if (s < 256) {
-                        if (op >= K.out_len) { err = INF_OUTPUT_OVERRUN; break; }
-                        tok_val[n_tok] = 0x80000000u | (uint32_t)s;
-                        tok_pos[n_tok] = (unsigned short)op;
-                        ++n_tok;
-                        ++op;
-                        continue;
-                    }
-                    if (s == 256) { in_block = false; if (last) done = true; break; }
-                    s -= 257;
-                    if (s >= 29) { err = INF_BAD_CODE; break; }
-                    int len;
-                    if (s < 8) len = 3 + s;
-                    else if (s == 28) len = 258;
-                    else {
-                        const int e = (s - 4) >> 2;
-                        len = 3 + ((4 + (s & 3)) << e) + (int)B.take(e);
-                    }
-                    B.refill();
-                    int d;
-                    const uint32_t dq = T.u16(IT_DFAST, (int)((uint32_t)B.bb & ((1u << IT_DFAST_BITS) - 1)));
-                    if (dq) {
-                        d = (int)(dq & 511u);
-                        B.bb >>= dq >> 9;
-                        B.bc -= (int)(dq >> 9);
-                    } else {
-                        d = infl_decode(T, B, IT_DST_SYM, IT_DST_THR, IT_DST_BASE, n_dst);
-                    }
-                    if (d < 0 || d >= 30) { err = INF_BAD_CODE; break; }
-                    int dist;
-                    if (d < 4) dist = 1 + d;
-                    else {
-                        const int e = (d >> 1) - 1;
-                        dist = 1 + ((2 + (d & 1)) << e) + (int)B.take(e);
-                    }
-                    if ((uint32_t)dist > op) { err = INF_BAD_DISTANCE; break; }
-                    if ((uint32_t)len > K.out_len - op) { err = INF_OUTPUT_OVERRUN; break; }
-                    tok_val[n_tok] = ((uint32_t)len << 16) | (uint32_t)dist;
-                    tok_pos[n_tok] = (unsigned short)op;
-                    ++n_tok;
-                    op += (uint32_t)len;
+                bitpos = B.bit_pos();
+            }
+            err = __builtin_amdgcn_readfirstlane(e0);
+            if (err) break;
+            bitpos = (uint32_t)__builtin_amdgcn_readfirstlane((int)bitpos);
+            in_block = __builtin_amdgcn_readfirstlane((int)in_block) != 0;
+            last = __builtin_amdgcn_readfirstlane((int)last) != 0;
+            n_lit = __builtin_amdgcn_readfirstlane(n_lit);
+            n_dst = __builtin_amdgcn_readfirstlane(n_dst);
+            stored_len = (uint32_t)__builtin_amdgcn_readfirstlane((int)stored_len);
+            __builtin_amdgcn_wave_barrier();                                  // the tables are there for everybody
+            if (stored_len & 0x80000000u) {
+                // a stored block: its bytes follow in the input; copied by the wavefront, then the reader goes on behind them
+                stored_len &= 0x7fffffffu;
+                stored_at = (uint32_t)__builtin_amdgcn_readfirstlane((int)stored_at);
+                const unsigned char* src = reinterpret_cast<const unsigned char*>(words) + stored_at;
+                for (uint32_t k = lane; k < stored_len; k += 64) {
+                    const unsigned char v = src[k];
+                    oring[(op + k) & (IW_OUT - 1)] = v;
+                    gout[op + k] = v;
                 }
-                if (!err && B.wi > n_words + 4) err = INF_INPUT_OVERRUN;   // the stream ran out inside a block
+                __builtin_amdgcn_wave_barrier();
+                op += stored_len;
+                if (last) { done = true; continue; }
+                const uint32_t next = stored_at + stored_len;
+                bitpos = 8u * next;
+                loaded = (next >> 2) & ~127u;                                 // the ring starts over at the reader's new place
+                feed(next >> 2);                                              // (slots are word index mod IW_IN_WORDS; `loaded` stays a multiple of 128)
+                continue;
             }
-        }
-        // ---- the wavefront: what lane 0 found ----
-        err = __builtin_amdgcn_readfirstlane(err);
-        if (err) break;
-        n_tok = __builtin_amdgcn_readfirstlane(n_tok);
-        done = __builtin_amdgcn_readfirstlane((int)done) != 0;
-        stored_len = (uint32_t)__builtin_amdgcn_readfirstlane((int)stored_len);
-        __builtin_amdgcn_wave_barrier();
-        if (stored_len & 0x80000000u) {
-            // a stored block: its bytes follow in the input; copied by the wavefront, then the reader starts behind them
-            stored_len &= 0x7fffffffu;
-            stored_at = (uint32_t)__builtin_amdgcn_readfirstlane((int)stored_at);
-            const uint32_t op0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)op);
-            const unsigned char* src = reinterpret_cast<const unsigned char*>(words) + stored_at;
-            for (uint32_t k = lane; k < stored_len; k += 64) {
-                const unsigned char v = src[k];
-                oring[(op0 + k) & (IW_OUT - 1)] = v;
-                gout[op0 + k] = v;
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (lane == 0) op += stored_len;
-            if (done) continue;                                               // it was the stream's last block
-            const uint32_t next = stored_at + stored_len;
-            loaded = (next >> 2) & ~127u;                                     // the ring starts over at the reader's new place
-            // (ring slots are word index mod IW_IN_WORDS, and `loaded` stays a multiple of 128)
-            feed(next >> 2);
-            if (lane == 0) B.start(next);
+            feed(bitpos >> 5);
             continue;
         }
-        if (n_tok > 0) {
-            const bool mine = lane < n_tok;
-            const uint32_t v = mine ? tok_val[lane] : 0x80000000u;
-            const uint32_t p = mine ? tok_pos[lane] : 0u;
-            // Everything goes into the ring in stream order -- the literals between two matches at once, then the match:
-            // a byte written at place q takes the slot of q - 32768, which nothing from q on can refer to (a write out
-            // of order could take a slot that an earlier match of the batch still has to read).
-            const bool lit = mine && (v & 0x80000000u);
-            int prev = 0;
-            unsigned long long matches = __ballot(mine && !(v & 0x80000000u));
-            while (matches) {                                                 // the matches in their order
-                const int t = __ffsll((long long)matches) - 1;
-                matches &= matches - 1;
-                if (lit && lane >= prev && lane < t) {
-                    oring[p & (IW_OUT - 1)] = (unsigned char)v;
-                    gout[p] = (unsigned char)v;
+        // ---- inside a block: the whole TOKEN that would start at each of the next 64 bits (a literal, or a length
+        // code with its extra bits, distance code and extra bits: at most 37 bits through the direct tables) ----
+        uint32_t kind = 0, tlen = 0, size = 0, dist = 0, lit = 0;             // kind: 0 stop here, 1 literal, 2 match
+        {
+            const uint32_t p = bitpos + (uint32_t)lane, w = p >> 5, sh = p & 31u;
+            const uint32_t a = iring[w & (IW_IN_WORDS - 1)], c = iring[(w + 1) & (IW_IN_WORDS - 1)], d = iring[(w + 2) & (IW_IN_WORDS - 1)];
+            uint64_t v = ((uint64_t)__builtin_amdgcn_alignbit(d, c, sh) << 32) | __builtin_amdgcn_alignbit(c, a, sh);
+            const uint32_t e = T.u16(IT_FAST, (int)((uint32_t)v & ((1u << IT_FAST_BITS) - 1)));
+            const uint32_t sym = e & 511u;
+            uint32_t used = e >> 9;
+            if (e != 0 && sym < 256u) {
+                kind = 1; tlen = used; size = 1; lit = sym;
+            } else if (e != 0 && sym > 256u && sym < 257u + 29u) {
+                const uint32_t s = sym - 257u;
+                v >>= used;
+                uint32_t x = s < 8u || s == 28u ? 0u : (s - 4u) >> 2;
+                const uint32_t len = s < 8u ? 3u + s : (s == 28u ? 258u : 3u + ((4u + (s & 3u)) << x) + ((uint32_t)v & ((1u << x) - 1u)));
+                v >>= x;
+                used += x;
+                const uint32_t dq = T.u16(IT_DFAST, (int)((uint32_t)v & ((1u << IT_DFAST_BITS) - 1)));
+                const uint32_t dsym = dq & 511u;
+                if (dq != 0 && dsym < 30u) {
+                    v >>= dq >> 9;
+                    used += dq >> 9;
+                    x = dsym < 4u ? 0u : (dsym >> 1) - 1u;
+                    dist = dsym < 4u ? 1u + dsym : 1u + ((2u + (dsym & 1u)) << x) + ((uint32_t)v & ((1u << x) - 1u));
+                    used += x;
+                    kind = 2; tlen = used; size = len;
                 }
-                prev = t + 1;
+            }
+        }
+        // The chain of true starts from bit 0: token after token while each one's source lies wholly before this pass's
+        // output (then the tokens of a pass do not depend on each other and their lanes write them side by side);
+        // a match that does not (a short distance, a long one that reaches the ring's far end, one of more than 32
+        // bytes) ends the chain and is taken on its own below, as are the end-of-block code and codes the direct
+        // tables do not hold.
+        unsigned long long starts = 0;
+        int j = 0;
+        uint32_t P = 0, mypos = 0;                                            // bytes this pass writes; where this lane's token goes
+        while (j < 64) {
+            const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)kind, j);
+            if (kj == 0) break;
+            const uint32_t sz = (uint32_t)__builtin_amdgcn_readlane((int)size, j);
+            if (sz > K.out_len - op - P) break;
+            if (kj == 2) {
+                const uint32_t dj = (uint32_t)__builtin_amdgcn_readlane((int)dist, j);
+                if (dj > op + P || dj < sz + P || sz > 32u || dj > (uint32_t)IW_OUT - 2304u) break;
+            }
+            mypos = lane == j ? op + P : mypos;
+            starts |= 1ull << j;
+            P += sz;
+            j += (int)__builtin_amdgcn_readlane((int)tlen, j);
+        }
+        if (starts) {
+            const bool mine = (starts >> lane) & 1ull;
+            if (mine && kind == 1) {
+                oring[mypos & (IW_OUT - 1)] = (unsigned char)lit;
+                gout[mypos] = (unsigned char)lit;
+            }
+            // matches: every lane its own, four bytes read, then written (sources lie before the pass: no order among them;
+            // at most 2 KiB are written in a pass, and no source is nearer than that to the ring's far end)
+            const uint32_t n_mine = mine && kind == 2 ? size : 0u;
+            uint32_t n_max = n_mine;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) n_max = max(n_max, (uint32_t)__shfl_xor((int)n_max, o));
+            for (uint32_t k0 = 0; k0 < n_max; k0 += 4) {
+                unsigned char x[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) x[q] = k0 + q < n_mine ? oring[(mypos - dist + k0 + q) & (IW_OUT - 1)] : (unsigned char)0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (k0 + q < n_mine) { oring[(mypos + k0 + q) & (IW_OUT - 1)] = x[q]; gout[mypos + k0 + q] = x[q]; }
+            }
+            op += P;
+            __builtin_amdgcn_wave_barrier();
+        }
+        bitpos += (uint32_t)j;
+        if (!starts) {
+            // ---- a token the chain could not take, decoded the ordinary way (every lane the same) ----
+            InflPeek P = peek64(bitpos);
+            const uint32_t ej = T.u16(IT_FAST, (int)((uint32_t)P.bb & ((1u << IT_FAST_BITS) - 1)));
+            int s;
+            if (ej != 0) {
+                s = (int)(ej & 511u);
+                P.bb >>= ej >> 9;
+                P.bc -= (int)(ej >> 9);
+            } else {
+                s = infl_decode(T, P, IT_LIT_SYM, IT_LIT_THR, IT_LIT_BASE, n_lit);
+                if (s < 0) { err = INF_BAD_CODE; break; }
+            }
+            if (s < 256) {
+                if (op >= K.out_len) { err = INF_OUTPUT_OVERRUN; break; }
+                if (lane == 0) { oring[op & (IW_OUT - 1)] = (unsigned char)s; gout[op] = (unsigned char)s; }
+                op += 1;
                 __builtin_amdgcn_wave_barrier();
-                const uint32_t mv = (uint32_t)__builtin_amdgcn_readlane((int)v, t);
-                const uint32_t mp = (uint32_t)__builtin_amdgcn_readlane((int)p, t);
-                const uint32_t len = mv >> 16, dist = mv & 0xffffu;
+            } else if (s == 256) {
+                in_block = false;
+                if (last) done = true;
+            } else {
+                s -= 257;
+                if (s >= 29) { err = INF_BAD_CODE; break; }
+                uint32_t len;
+                if (s < 8) len = 3u + (uint32_t)s;
+                else if (s == 28) len = 258u;
+                else {
+                    const int x = (s - 4) >> 2;
+                    len = 3u + ((4u + ((uint32_t)s & 3u)) << x) + ((uint32_t)P.bb & ((1u << x) - 1u));
+                    P.bb >>= x;
+                    P.bc -= x;
+                }
+                int d;
+                const uint32_t dq = T.u16(IT_DFAST, (int)((uint32_t)P.bb & ((1u << IT_DFAST_BITS) - 1)));
+                if (dq) {
+                    d = (int)(dq & 511u);
+                    P.bb >>= dq >> 9;
+                    P.bc -= (int)(dq >> 9);
+                } else {
+                    d = infl_decode(T, P, IT_DST_SYM, IT_DST_THR, IT_DST_BASE, n_dst);
+                }
+                if (d < 0 || d >= 30) { err = INF_BAD_CODE; break; }
+                uint32_t dist;
+                if (d < 4) dist = 1u + (uint32_t)d;
+                else {
+                    const int x = (d >> 1) - 1;
+                    dist = 1u + ((2u + ((uint32_t)d & 1u)) << x) + ((uint32_t)P.bb & ((1u << x) - 1u));
+                    P.bb >>= x;
+                    P.bc -= x;
+                }
+                if (dist > op) { err = INF_BAD_DISTANCE; break; }
+                if (len > K.out_len - op) { err = INF_OUTPUT_OVERRUN; break; }
                 if (dist >= 64) {
                     // 64 bytes per step: a step's source lies wholly before what the step writes
                     for (uint32_t k = lane; k < len; k += 64) {
-                        const unsigned char x = oring[(mp - dist + k) & (IW_OUT - 1)];
-                        oring[(mp + k) & (IW_OUT - 1)] = x;
-                        gout[mp + k] = x;
+                        const unsigned char x = oring[(op - dist + k) & (IW_OUT - 1)];
+                        oring[(op + k) & (IW_OUT - 1)] = x;
+                        gout[op + k] = x;
                     }
                 } else {
                     // a period shorter than the wavefront: every byte is one of the `dist` bytes before the match
                     const uint32_t m = (uint32_t)lane % dist;
-                    const unsigned char x = oring[(mp - dist + m) & (IW_OUT - 1)];
+                    const unsigned char x = oring[(op - dist + m) & (IW_OUT - 1)];
                     const uint32_t span = dist * (64u / dist);                // bytes per step: whole periods
-                    for (uint32_t k = lane; k < len; k += span) {
-                        if ((uint32_t)lane < span) {
-                            oring[(mp + k) & (IW_OUT - 1)] = x;
-                            gout[mp + k] = x;
+                    if ((uint32_t)lane < span) {
+                        for (uint32_t k = lane; k < len; k += span) {
+                            oring[(op + k) & (IW_OUT - 1)] = x;
+                            gout[op + k] = x;
                         }
                     }
                 }
+                op += len;
                 __builtin_amdgcn_wave_barrier();
             }
-            if (lit && lane >= prev) {                                        // the literals behind the last match
-                oring[p & (IW_OUT - 1)] = (unsigned char)v;
-                gout[p] = (unsigned char)v;
-            }
-            __builtin_amdgcn_wave_barrier();
+            bitpos += (uint32_t)(64 - P.bc);
         }
-        feed((uint32_t)__builtin_amdgcn_readfirstlane((int)B.wi));
+        feed(bitpos >> 5);
     }
     if (!err && !done) err = INF_INPUT_OVERRUN;                               // the pass limit: no valid stream gets here
-    if (!err && (uint32_t)__builtin_amdgcn_readfirstlane((int)op) != K.out_len) err = INF_SIZE_MISMATCH;
+    if (!err && op != K.out_len) err = INF_SIZE_MISMATCH;
     if (lane == 0) status[b] = err;
 }
 

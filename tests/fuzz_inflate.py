@@ -61,7 +61,7 @@ def main():
         raw = _bgzf(chunks, level, strategy)
         prefix = rng.integers(0, 256, int(rng.integers(0, 3000)), dtype=np.uint8).tobytes()
         cut = len(raw) - int(rng.integers(0, 2)) * int(rng.integers(1, 12))
-        inf.set_lanes(int(rng.choice([8, 16, 32])))
+        inf.set_lanes(int(rng.choice([1, 1, 1, 8, 32])))
         got, eaten = inf.inflate(raw[:cut], prefix)
         whole = cut == len(raw)
         want = prefix + b"".join(chunks if whole else chunks[:-1])
