@@ -95,28 +95,39 @@ def call_chunks(chunks, args, tmpdir):
             out.append(a if k == 0 else bamio.drop_before(a, lo))
         return out
 
-    def load(unit, pieces=None):                          # fetch, inflate, decode, filter and trim: all outside the lock
+    bam_names = args.bamFiles.split(",")
+
+    def load_bam(unit, bi, pieces=None):
+        """the read buffer of one BAM file for the unit's stretch: fetch, inflate, decode, filter and trim"""
         (chrom, _, _), s, e = unit
-        if not hasattr(local, "readers"):                 # a file handle per helper thread
-            local.readers = [bamio.BamReader(b, inflater=inflaters) for b in args.bamFiles.split(",")]
-            opened.extend(local.readers)
-        bufs = []
-        for bi, r in enumerate(local.readers):
-            t0 = time.perf_counter()
-            if pieces is not None:                        # the stretch was read in pieces side by side
-                got = [p.result()[bi] for p in pieces]
-                reads = bamio._concat([a for a in got if len(a["pos"])])
-            else:
-                try:
-                    reads = r.fetch(chrom, s, e)
-                except KeyError:                          # this BAM has no such sequence: no reads from it
-                    reads = bamio._concat([])
-            reads["chrom"] = chrom.encode()
-            t1 = time.perf_counter()
-            bufs.append(simulate.buffer_of(reads, s, e, minMapQual=opts.minMapQual, maxReads=int(opts.maxReads),
-                                           minGoodQualBases=opts.minGoodQualBases, maxBadQualBases=opts.maxBadQualBases))
-            spent["fetch"] += t1 - t0
-            spent["buffers"] += time.perf_counter() - t1
+        if not hasattr(local, "readers"):                 # a file handle per helper thread and file, opened when first used
+            local.readers = {}
+        if bi not in local.readers:
+            local.readers[bi] = bamio.BamReader(bam_names[bi], inflater=inflaters)
+            opened.append(local.readers[bi])
+        t0 = time.perf_counter()
+        if pieces is not None:                            # the stretch was read in pieces side by side
+            got = [p.result()[bi] for p in pieces]
+            reads = bamio._concat([a for a in got if len(a["pos"])])
+        else:
+            try:
+                reads = local.readers[bi].fetch(chrom, s, e)
+            except KeyError:                              # this BAM has no such sequence: no reads from it
+                reads = bamio._concat([])
+        reads["chrom"] = chrom.encode()
+        t1 = time.perf_counter()
+        buf = simulate.buffer_of(reads, s, e, minMapQual=opts.minMapQual, maxReads=int(opts.maxReads),
+                                 minGoodQualBases=opts.minGoodQualBases, maxBadQualBases=opts.maxBadQualBases)
+        spent["fetch"] += t1 - t0
+        spent["buffers"] += time.perf_counter() - t1
+        return buf
+
+    def load(unit, pieces=None, per_bam=None):            # fetch, inflate, decode, filter and trim: all outside the lock
+        (chrom, _, _), s, e = unit
+        if per_bam is not None:                           # every file's buffer was made by a task of its own
+            bufs = [f.result() for f in per_bam]
+        else:
+            bufs = [load_bam(unit, bi, pieces) for bi in range(len(bam_names))]
         if sum(b.readCount for b in bufs) > opts.maxReads:                # variantcaller.pyx:84-88: the stretch is skipped
             return bufs, None
         t2 = time.perf_counter()
@@ -139,7 +150,12 @@ def call_chunks(chunks, args, tmpdir):
         # time one helper thread needs to prepare it: the first stretches are read in pieces (12, 6, 4, 3, 2, 2 of them
         # with twelve helper threads), queued in the order of the stretches, so that the helpers finish stretch 0 together
         # first, then stretch 1, ... instead of every helper starting a whole stretch of its own.
+        # With many BAM files a stretch's files are read side by side instead (one task per file, queued before the
+        # task that waits for them: the pool starts tasks in the order they were queued, so a waiting task never holds
+        # up what it waits for).
         def submit(k, unit):
+            if len(bam_names) >= 4:
+                return pool.submit(load, unit, None, [pool.submit(load_bam, unit, bi) for bi in range(len(bam_names))])
             parts = max(1, ahead // (k + 1)) if k < ahead else 1
             if parts <= 1:
                 return pool.submit(load, unit)

@@ -89,6 +89,21 @@ def test_file_to_file_run_equals_the_restatements_end_to_end(tmp_path, inflate):
     assert got == want
 
 
+@pytest.mark.gpu
+def test_file_to_file_run_of_fifty_bam_files_equals_the_restatements(tmp_path):
+    """the joint-calling configuration from files: 50 BAM files (one read buffer each per stretch,
+    variantcaller.pyx:82-90; one individual each, cpopulation.pyx:698-725) -> one VCF with 50 sample columns, against
+    the chained CPU restatements.  Byte-identical body lines.  (Each stretch's 50 files are read side by side by the
+    runner's helper threads.)"""
+    got, want, skipped = vc.files_both(str(tmp_path), 77, inflate="device", G=30000, unit=10000, chunk=15000, n_var=36,
+                                       spacing=350, coverage=7, n_samples=50, homopolymers=8)
+    assert not skipped
+    assert len(want) > 20 and all(len(l.split("\t")) == 9 + 50 for l in want)
+    diff = vc.classify(got, want)
+    assert not diff, {k: v[:3] for k, v in diff.items()}
+    assert got == want
+
+
 def test_equal_posteriors_stay_equal_in_the_ranking_of_a_crowded_window(tmp_path):
     """a window with more candidates than maxVariants keeps the ones with the highest posteriors (variantcaller.pyx:142-166);
     here four SNPs with two supporting reads each stand beside a deletion with exactly equal inputs, their posteriors are
