@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 5
+#define PG_ABI_VERSION 6
 
 enum {
     PG_OK = 0,
@@ -196,9 +196,36 @@ int pg_align_pairs(pg_ctx *ctx, int64_t n_pairs, const int32_t *hap_idx, const i
                    int32_t *score, int32_t *anchor, double *likelihood);
 
 /*
- * pg_align_pairs for callers that cannot allocate device memory: code under HIP
- * graph capture, tight serving loops, harnesses that forbid hipMalloc.  It has
- * no counterpart in the reference.  Same computation and results as
+ * One window in one call: every haplotype against every read, haplotype-major
+ * (pair h * n_reads + r), the matrix the reference fills for a window by calling
+ * Haplotype.alignReads for each of its haplotypes (platypus/chaplotype.pyx:239-270,
+ * from platypus/cgenotype.pyx:55-56), each of which walks the window's reads
+ * through alignNoTraceback (platypus/calign.pyx:36-78).  Arguments as for
+ * pg_haps_upload and pg_reads_upload, outputs as for pg_results_fetch
+ * (n_haps * n_reads elements each, likelihood may be NULL); the same values as
+ * pg_haps_upload + pg_reads_upload + pg_pairs_block + pg_align_launch +
+ * pg_results_fetch give, and the same errors.  It is the call for a caller that
+ * works window by window, as the reference does: the host lays the window out as
+ * one block in pinned memory, one copy takes it to the device, one kernel makes
+ * every array the anchoring and alignment kernels read, and one copy and one wait
+ * bring the results back (the five calls above make some twenty copies and four
+ * waits).  Windows of more than 2^20 pairs or 16 Mi sequence elements, and windows
+ * with indel-bearing haplotypes whose reads are longer than 263 bases, are passed
+ * through those five calls.  Afterwards the context holds no uploaded batch;
+ * the results stay on the device for pg_genotype_loglik, the caller stage and
+ * pg_results_fetch, as after pg_align_launch (pg_kernel_time_ms has nothing to
+ * report for this call: its kernels are not bracketed by events).
+ */
+int pg_align_window(pg_ctx *ctx, int n_haps, const char *hap_seq, const int64_t *hap_off, const int32_t *hap_start_pos,
+                    const int32_t *hap_var_seq_len, int n_reads, const char *read_seq, const char *read_qual,
+                    const int64_t *read_off, const int32_t *read_pos, const int32_t *read_mapq,
+                    int32_t *score, int32_t *anchor, double *likelihood);
+
+/*
+ * pg_align_pairs for callers that cannot allocate device memory: tight serving
+ * loops, harnesses that forbid hipMalloc, code between two captured HIP graphs
+ * (the call itself cannot be captured: it waits for the stream and reads status
+ * words back).  It has no counterpart in the reference.  Same computation and results as
  * pg_align_pairs on the uploaded haplotypes and reads, but
  *   - the pair indices and the three outputs are DEVICE pointers of the caller
  *     (n_pairs elements each; d_likelihood may be NULL),

@@ -123,11 +123,9 @@ cdef int alignBatch(int nHaps, char** hapSeqs, int* hapStarts, int* varSeqLens, 
         memcpy(sbuf + roff[r], start[r].seq, start[r].rlen)
         memcpy(qbuf + roff[r], start[r].qual, start[r].rlen)
     try:
-        check(pg_haps_upload(g_ctx, nHaps, hbuf, hoff, <int32_t*>hapStarts, <int32_t*>varSeqLens))
-        check(pg_reads_upload(g_ctx, nReads, sbuf, qbuf, roff, rpos, rmq))
-        check(pg_pairs_block(g_ctx, 0, nHaps, 0, nReads))
-        check(pg_align_launch(g_ctx))
-        check(pg_results_fetch(g_ctx, <int32_t*>scores, <int32_t*>anchors, likelihoods))
+        # one block up, one kernel for the device arrays, anchoring, alignment, one block back
+        check(pg_align_window(g_ctx, nHaps, hbuf, hoff, <int32_t*>hapStarts, <int32_t*>varSeqLens, nReads, sbuf, qbuf, roff,
+                              rpos, rmq, <int32_t*>scores, <int32_t*>anchors, likelihoods))
     finally:
         free(hoff); free(hbuf); free(roff); free(rpos); free(rmq); free(sbuf); free(qbuf)
     return 0

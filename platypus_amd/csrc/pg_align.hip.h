@@ -418,6 +418,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // run = number of following equal bases, an 'N' never extends a run, capped at
 // `cap` (table length - 1): the count of align.c:73-90 before its cut at the
 // slice end.  *bad_byte is set if a base has no code (SeqCodes).
+// one haplotype by one workgroup; returns whether this thread met a base without a code
+__device__ __forceinline__ bool pack_hapx_one(const uint8_t* __restrict__ src, int len, uint16_t* __restrict__ dst,
+                                              const SeqCodes* __restrict__ codes, int pad, int cap)
+{
+    bool bad = false;
+    for (int p = threadIdx.x; p < len + pad; p += blockDim.x) {
+        uint32_t c = 'N', r = 0;
+        if (p < len) {
+            c = src[p];
+            bad |= codes->read[c] == 0;
+            if (c != 'N')
+                while ((int)r < cap && p + (int)r + 1 < len && src[p + r + 1] == c) ++r;
+        }
+        dst[p] = (uint16_t)((r << 9) | (c << 1));
+    }
+    return bad;
+}
+
 __global__ __launch_bounds__(256) void k_pack_hapx(const uint8_t* __restrict__ src,
                                                    const int64_t* __restrict__ soff,
                                                    const int64_t* __restrict__ xoff,
@@ -426,25 +444,29 @@ __global__ __launch_bounds__(256) void k_pack_hapx(const uint8_t* __restrict__ s
 {
     for (int h = blockIdx.x; h < n_haps; h += gridDim.x) {
         const int64_t s0 = soff[h];
-        const int len = (int)(soff[h + 1] - s0);
-        const int64_t d0 = xoff[h];
-        bool bad = false;
-        for (int p = threadIdx.x; p < len + pad; p += blockDim.x) {
-            uint32_t c = 'N', r = 0;
-            if (p < len) {
-                c = src[s0 + p];
-                bad |= codes->read[c] == 0;
-                if (c != 'N')
-                    while ((int)r < cap && p + (int)r + 1 < len && src[s0 + p + r + 1] == c) ++r;
-            }
-            dst[d0 + p] = (uint16_t)((r << 9) | (c << 1));
-        }
-        if (bad) atomicOr(bad_byte, 2);
+        if (pack_hapx_one(src + s0, (int)(soff[h + 1] - s0), dst + xoff[h], codes, pad, cap)) atomicOr(bad_byte, 2);
     }
 }
 
 // readx[xoff[r] + j] = quality << 9 | char << 1 for j < len, kPadElem up to xoff[r+1].
 // *bad is set to 1 if any quality byte has its top bit set, to 2 if a base has no code.
+// one read by one wavefront: `tot` elements; returns the flags this lane saw (1 a quality above 127, 2 a base without a code)
+__device__ __forceinline__ int pack_readx_one(const uint8_t* __restrict__ seq, const uint8_t* __restrict__ qual, int len,
+                                              uint16_t* __restrict__ dst, int tot, const SeqCodes* __restrict__ codes, int lane)
+{
+    uint32_t seen = 0;
+    bool no_code = false;
+    for (int j = lane; j < tot; j += 64) {
+        const uint32_t q = j < len ? qual[j] : 0u;
+        const uint32_t c = j < len ? seq[j] : (uint32_t)'A';
+        seen |= q;
+        no_code |= codes->read[c] == 0;
+        dst[j] = j < len ? (uint16_t)(((q & 0x7fu) << 9) | (c << 1)) : (uint16_t)kPadElem;
+    }
+    // qualities above 127 are outside the domain (the reference reads them as signed char)
+    return ((seen & 0x80u) ? 1 : 0) | (no_code ? 2 : 0);
+}
+
 __global__ __launch_bounds__(256) void k_pack_readx(const uint8_t* __restrict__ seq,
                                                     const uint8_t* __restrict__ qual,
                                                     const int64_t* __restrict__ roff,
@@ -456,21 +478,9 @@ __global__ __launch_bounds__(256) void k_pack_readx(const uint8_t* __restrict__ 
     const int n_waves = (int)(gridDim.x * 4u);
     for (int r = wave; r < n_reads; r += n_waves) {
         const int64_t s0 = roff[r];
-        const int len = (int)(roff[r + 1] - s0);
         const int64_t d0 = xoff[r];
-        const int tot = (int)(xoff[r + 1] - d0);
-        uint32_t seen = 0;
-        bool no_code = false;
-        for (int j = lane; j < tot; j += 64) {
-            const uint32_t q = j < len ? qual[s0 + j] : 0u;
-            const uint32_t c = j < len ? seq[s0 + j] : (uint32_t)'A';
-            seen |= q;
-            no_code |= codes->read[c] == 0;
-            dst[d0 + j] = j < len ? (uint16_t)(((q & 0x7fu) << 9) | (c << 1)) : (uint16_t)kPadElem;
-        }
-        // qualities above 127 are outside the domain (the reference reads them as signed char)
-        if (seen & 0x80u) atomicOr(bad, 1);
-        if (no_code) atomicOr(bad, 2);
+        const int f = pack_readx_one(seq + s0, qual + s0, (int)(roff[r + 1] - s0), dst + d0, (int)(xoff[r + 1] - d0), codes, lane);
+        if (f) atomicOr(bad, f);
     }
 }
 

@@ -46,6 +46,21 @@ __device__ __forceinline__ uint32_t nuc_code(uint32_t ch) {
 // word off2[s]; rows end with two zero words, so the 64-bit window of any 7-mer
 // start can be read without a bounds test.
 // ---------------------------------------------------------------------------
+// one row: words first, first + step, ... of the nw words of a sequence of len bytes at seq
+__device__ __forceinline__ void pack_codes_row(const uint8_t* __restrict__ seq, int len, uint32_t* __restrict__ dst, int nw,
+                                               int first, int step)
+{
+    for (int w = first; w < nw; w += step) {
+        uint32_t bits = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int p = w * 16 + j;
+            if (p < len) bits |= nuc_code(seq[p]) << (2 * j);
+        }
+        dst[w] = bits;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_pack_codes(const uint8_t* __restrict__ seq,
                                                     const int64_t* __restrict__ soff,
                                                     const int64_t* __restrict__ off2,
@@ -55,18 +70,8 @@ __global__ __launch_bounds__(256) void k_pack_codes(const uint8_t* __restrict__ 
     const int n_waves = (int)(gridDim.x * 4u);
     for (int s = wave; s < n_seq; s += n_waves) {
         const int64_t s0 = soff[s];
-        const int len = (int)(soff[s + 1] - s0);
         const int64_t d0 = off2[s];
-        const int nw = (int)(off2[s + 1] - d0);
-        for (int w = lane; w < nw; w += 64) {
-            uint32_t bits = 0;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int p = w * 16 + j;
-                if (p < len) bits |= nuc_code(seq[s0 + p]) << (2 * j);
-            }
-            dst[d0 + w] = bits;
-        }
+        pack_codes_row(seq + s0, (int)(soff[s + 1] - s0), dst + d0, (int)(off2[s + 1] - d0), lane, 64);
     }
 }
 
@@ -536,14 +541,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // packed bases, in the same layout: bit 2 (p % 16) of word p / 16.
 // One workgroup per haplotype; the 16384-entry table of the reference in LDS.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_hap_unique(const uint32_t* __restrict__ hap2, const VoteHap* __restrict__ vh,
-                                                    uint32_t* __restrict__ hapU, uint32_t* __restrict__ hapUbits)
+// one haplotype by one workgroup of 256 threads: hw its packed row, U / Ubits the rows to write
+__device__ __forceinline__ void hap_unique_one(const uint32_t* __restrict__ hw, int len, uint32_t* __restrict__ U,
+                                               uint32_t* __restrict__ Ubits)
 {
     __shared__ uint16_t tab[kHashSize];
     const int tid = threadIdx.x;
-    const VoteHap H = vh[blockIdx.x];
-    const uint32_t* hw = hap2 + H.hap2off;
-    const int nk = H.len - kHashNucs;
+    const int nk = len - kHashNucs;
     {
         uint4* z = reinterpret_cast<uint4*>(tab);
         for (int i = tid; i < kHashSize / 8; i += 256) z[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
@@ -556,7 +560,7 @@ __global__ __launch_bounds__(256) void k_hap_unique(const uint32_t* __restrict__
         if (tab[k] != (uint16_t)(i + 1)) tab[k] = 0xffffu;
     }
     __syncthreads();
-    const int nw = (H.len + 15) / 16 + 2;
+    const int nw = (len + 15) / 16 + 2;
     for (int w = tid; w < nw; w += 256) {
         uint32_t bits = 0;
 #pragma unroll
@@ -564,15 +568,22 @@ __global__ __launch_bounds__(256) void k_hap_unique(const uint32_t* __restrict__
             const int i = 16 * w + k;
             if (i < nk && tab[hash7_packed(hw, i)] == (uint16_t)(i + 1)) bits |= 1u << (2 * k);
         }
-        hapU[H.hap2off + w] = bits;
+        U[w] = bits;
     }
     // ... and which 7-mer VALUES are owned by a unique start: one bit per value, 512 words per haplotype
     for (int w = tid; w < kHashSize / 32; w += 256) {
         uint32_t bits = 0;
 #pragma unroll
         for (int k = 0; k < 32; ++k) bits |= (uint32_t)(tab[32 * w + k] != 0xffffu) << k;
-        hapUbits[(size_t)blockIdx.x * (kHashSize / 32) + w] = bits;
+        Ubits[w] = bits;
     }
+}
+
+__global__ __launch_bounds__(256) void k_hap_unique(const uint32_t* __restrict__ hap2, const VoteHap* __restrict__ vh,
+                                                    uint32_t* __restrict__ hapU, uint32_t* __restrict__ hapUbits)
+{
+    const VoteHap H = vh[blockIdx.x];
+    hap_unique_one(hap2 + H.hap2off, H.len, hapU + H.hap2off, hapUbits + (size_t)blockIdx.x * (kHashSize / 32));
 }
 
 // ---------------------------------------------------------------------------

@@ -21,6 +21,7 @@
 #include "pg_prep.hip.h"
 #include "pg_caller.hip.h"
 #include "pg_inflate.hip.h"
+#include "pg_window.hip.h"
 
 namespace {
 
@@ -106,6 +107,7 @@ struct pg_ctx {
     DevBuf<pg::SeqCodes> d_codes;        // code tables of the sequence bytes (pg_align.hip.h)
     // kernel-choice overrides of pg_set_option (tests and measurements); 0 / -1 = the library decides
     int vote_waves = 0;                  // "vote_waves": wavefronts per workgroup of the vote kernel
+    int vote5_lds = 0;                   // dynamic LDS k_vote5 has been allowed so far
     int vote_kernel = -1;                // "vote_kernel": 0 position table in LDS (k_vote4), 1 bit-parallel counts (k_vote5)
     int lds_pad = 0;                     // "align_lds_pad": extra LDS per workgroup of the DP kernel, lowers its occupancy
     int gl_kernel = -1;                  // "gl_kernel": 0 cell, 1 tile
@@ -152,9 +154,21 @@ struct pg_ctx {
     DevBuf<int32_t> d_blk32;             // block descriptors of pg_pairs_blocks
     DevBuf<int64_t> d_blk_base;
     pg::PairWork work;                   // the arrays above, as the kernels take them
+    std::vector<int64_t> win_tmp;        // pg_align_window's host scratch
+    std::vector<int32_t> win_tmp32;
 
-    // results
+    // one window per call (pg_align_window): the block the host fills and its copy on the device
+    uint8_t* h_win = nullptr;
+    size_t h_win_cap = 0;
+    DevBuf<uint8_t> d_win;
+
+    // results: where the last launch put them (the arrays below, or pg_align_window's block) and how many pairs they are of
     bool launched = false;
+    int64_t n_results = 0;
+    const int32_t* r_score = nullptr;
+    const int32_t* r_anchor = nullptr;
+    const double* r_like = nullptr;
+    const int32_t* r_status = nullptr;   // status words of that launch's pair list
     DevBuf<int32_t> d_score, d_anchor;
     DevBuf<double> d_like;
 
@@ -255,9 +269,33 @@ unsigned prep_grid(int64_t n_pairs) { return (unsigned)std::min<int64_t>((n_pair
 
 // wavefronts of the alignment kernel: exact for a uniform batch, an upper bound for a ragged one
 // (every read length present may end with a partly filled wavefront)
-int wave_bound(const pg_ctx* c, int64_t np) {
+int wave_bound(bool uniform, int max_rlen, int64_t np) {
     const int64_t full = (np + 63) / 64;
-    return (int)(c->uniform_rlen ? full : full + std::min<int64_t>(np, c->max_rlen));
+    return (int)(uniform ? full : full + std::min<int64_t>(np, max_rlen));
+}
+int wave_bound(const pg_ctx* c, int64_t np) { return wave_bound(c->uniform_rlen, c->max_rlen, np); }
+
+// what the anchoring and alignment kernels read of a haplotype batch and a read batch
+struct AlignBufs {
+    const uint16_t* hapx; const int64_t* hap_doff; const int32_t* hap_len; const int32_t* hap_start; const int32_t* hap_varlen;
+    const uint32_t* hap2; const uint32_t* hapU; const uint32_t* hapUbits; const pg::VoteHap* vh;
+    const uint16_t* readx; const int64_t* read_xoff; const uint32_t* read2; const int32_t* read_pos; const int32_t* read_mapq;
+    int n_vote_haps, max_rlen, max_hap_len;
+    bool uniform;
+    int n_waves;          // wavefronts of the alignment kernel (ragged: an upper bound, the count is in the status words)
+    bool timed;           // record the context's events around the kernels and clear the anchoring counters first
+};
+
+AlignBufs ctx_bufs(const pg_ctx* c, int64_t np) {
+    AlignBufs B;
+    B.hapx = c->d_hapx.p; B.hap_doff = c->d_hap_doff.p; B.hap_len = c->d_hap_len.p; B.hap_start = c->d_hap_start.p;
+    B.hap_varlen = c->d_hap_varlen.p; B.hap2 = c->d_hap2.p; B.hapU = c->d_hapU.p; B.hapUbits = c->d_hapUbits.p; B.vh = c->d_vh.p;
+    B.readx = c->d_readx.p; B.read_xoff = c->d_read_xoff.p; B.read2 = c->d_read2.p; B.read_pos = c->d_read_pos.p;
+    B.read_mapq = c->d_read_mapq.p;
+    B.n_vote_haps = c->n_vote_haps; B.max_rlen = c->max_rlen; B.max_hap_len = c->max_hap_len; B.uniform = c->uniform_rlen;
+    B.n_waves = wave_bound(c, np);
+    B.timed = true;
+    return B;
 }
 
 // Enqueue the preparation of `np` pairs (device arrays pair_hap / pair_read) into W.
@@ -319,66 +357,73 @@ int finish_pairs(pg_ctx* c, int64_t np) {
 }
 
 // Enqueue anchoring + alignment of a prepared pair list; results go to score / anchor / like (device).
-int enqueue_align(pg_ctx* c, const pg::PairWork& W, const int32_t* pair_hap, const int32_t* pair_read, int64_t np,
+int enqueue_align(pg_ctx* c, const AlignBufs& U, const pg::PairWork& W, const int32_t* pair_hap, const int32_t* pair_read, int64_t np,
                   int32_t* score, int32_t* anchor, double* like) {
     // anchoring of pairs on indel-bearing haplotypes
-    PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_ANCHOR], c->stream));
+    if (U.timed) PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_ANCHOR], c->stream));
     // reads of up to 263 bases (sixteen 16-base groups) take the table-free kernel
-    const bool bits = c->vote_kernel >= 0 ? (c->vote_kernel == 1 && c->max_rlen <= 263) : c->max_rlen <= 263;
-    if (c->n_vote_haps > 0 && bits) {
-        PG_HIP(c, hipMemsetAsync(W.status + pg::ST_N_NAMED, 0, 2 * sizeof(int32_t), c->stream));   // counted per launch
-        const int pad = (c->max_rlen + 15) / 16 + 3;
-        const int row_cap = (c->max_hap_len + 15) / 16 + 2 + 2 * pad;
+    const bool bits = c->vote_kernel >= 0 ? (c->vote_kernel == 1 && U.max_rlen <= 263) : U.max_rlen <= 263;
+    if (U.n_vote_haps > 0 && bits) {
+        if (U.timed) PG_HIP(c, hipMemsetAsync(W.status + pg::ST_N_NAMED, 0, 2 * sizeof(int32_t), c->stream));   // counted per launch
+        const int pad = (U.max_rlen + 15) / 16 + 3;
+        const int row_cap = (U.max_hap_len + 15) / 16 + 2 + 2 * pad;
         // one lane per pair: a workgroup takes the next 64 * n_wav vote records, whatever haplotypes they are on
         const int n_wav = c->vote_waves > 0 ? std::min(c->vote_waves, 4) : 2;
         const size_t lds = ((size_t)pg::kVoteSlots * (2 * (size_t)row_cap + pg::kCandSlots / 2) + (size_t)n_wav * 20) * 4;
         if (lds > 160 * 1024)
-            return fail(c, PG_ERR_UNSUPPORTED, "anchoring rows for haplotype length %d need %zu bytes of LDS", c->max_hap_len, lds);
-        PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_vote5), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            return fail(c, PG_ERR_UNSUPPORTED, "anchoring rows for haplotype length %d need %zu bytes of LDS", U.max_hap_len, lds);
+        if ((int)lds > c->vote5_lds) {
+            PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_vote5), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            c->vote5_lds = (int)lds;
+        }
         const int64_t grid = (np + 64 * n_wav - 1) / (64 * n_wav);          // records <= pairs; workgroups past the last record return
-        hipLaunchKernelGGL(pg::k_vote5, dim3((unsigned)grid), dim3(64 * n_wav), lds, c->stream, c->d_hap2.p, c->d_hapU.p,
-                           c->d_hapUbits.p, c->d_read2.p, c->d_vh.p, W.hap_cnt, W.recs, W.status, W.anchor_in, pad, row_cap,
-                           c->n_vote_haps);
+        hipLaunchKernelGGL(pg::k_vote5, dim3((unsigned)grid), dim3(64 * n_wav), lds, c->stream, U.hap2, U.hapU,
+                           U.hapUbits, U.read2, U.vh, W.hap_cnt, W.recs, W.status, W.anchor_in, pad, row_cap,
+                           U.n_vote_haps);
         PG_HIP(c, hipGetLastError());
-    } else if (c->n_vote_haps > 0) {
-        int cnt_stride = c->max_hap_len + c->max_rlen + 8;
+    } else if (U.n_vote_haps > 0) {
+        int cnt_stride = U.max_hap_len + U.max_rlen + 8;
         cnt_stride += cnt_stride & 1;
-        const int row_words = (c->max_rlen + 15) / 16 + 2;
+        const int row_words = (U.max_rlen + 15) / 16 + 2;
         // four lanes per read, four wavefronts per haplotype
         int n_wav = c->vote_waves > 0 ? std::min(c->vote_waves, 4) : 4;
         auto lds_bytes = [&](int w) { return (size_t)pg::kHashSize * 2 + (size_t)w * (cnt_stride * 2 + row_words * 4); };
         while (n_wav > 1 && lds_bytes(n_wav) > 160 * 1024) n_wav >>= 1;
         const size_t lds = lds_bytes(n_wav);
         if (lds > 160 * 1024)
-            return fail(c, PG_ERR_UNSUPPORTED, "vote counters for haplotype length %d need %zu bytes of LDS", c->max_hap_len, lds);
+            return fail(c, PG_ERR_UNSUPPORTED, "vote counters for haplotype length %d need %zu bytes of LDS", U.max_hap_len, lds);
         PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_vote4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(pg::k_vote4, dim3(c->n_vote_haps), dim3(64 * n_wav), lds, c->stream, c->d_hap2.p,
-                           c->d_read2.p, c->d_vh.p, W.hap_cnt, W.recs, W.status, W.anchor_in, cnt_stride, row_words);
+        hipLaunchKernelGGL(pg::k_vote4, dim3(U.n_vote_haps), dim3(64 * n_wav), lds, c->stream, U.hap2,
+                           U.read2, U.vh, W.hap_cnt, W.recs, W.status, W.anchor_in, cnt_stride, row_words);
         PG_HIP(c, hipGetLastError());
     }
-    PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_ANCHOR + 1], c->stream));
-    c->ev_valid[PG_K_ANCHOR] = true;
+    if (U.timed) {
+        PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_ANCHOR + 1], c->stream));
+        c->ev_valid[PG_K_ANCHOR] = true;
+    }
 
-    const int n_waves = wave_bound(c, np);
+    const int n_waves = U.n_waves;
     pg::Align2Args B;
-    B.hapx = c->d_hapx.p; B.hap_xoff = c->d_hap_doff.p; B.hap_len = c->d_hap_len.p;
-    B.hap_start = c->d_hap_start.p; B.hap_varlen = c->d_hap_varlen.p;
-    B.readx = c->d_readx.p; B.read_xoff = c->d_read_xoff.p;
-    B.read_pos = c->d_read_pos.p; B.read_mapq = c->d_read_mapq.p;
+    B.hapx = U.hapx; B.hap_xoff = U.hap_doff; B.hap_len = U.hap_len;
+    B.hap_start = U.hap_start; B.hap_varlen = U.hap_varlen;
+    B.readx = U.readx; B.read_xoff = U.read_xoff;
+    B.read_pos = U.read_pos; B.read_mapq = U.read_mapq;
     B.pair_hap = pair_hap; B.pair_read = pair_read;
     B.order = W.order; B.waves = W.waves; B.status = W.status;
     B.anchor_in = W.anchor_in; B.tab = c->d_tab1.p; B.codes = c->d_codes.p;
     B.exp_score = c->d_exp_score.p; B.exp_mapq = c->d_exp_mapq.p;
     B.score = score; B.anchor = anchor; B.like = like;
-    B.n_waves = n_waves; B.uniform_len = c->max_rlen; B.n_pairs = (int)np;
+    B.n_waves = n_waves; B.uniform_len = U.max_rlen; B.n_pairs = (int)np;
     B.ge = c->gapextend; B.np = c->nucprior;
     if (c->lds_pad > 0)
         PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_align2), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_pad));
-    PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_ALIGN], c->stream));
+    if (U.timed) PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_ALIGN], c->stream));
     hipLaunchKernelGGL(pg::k_align2, dim3((n_waves + 3) / 4), dim3(256), c->lds_pad, c->stream, B);
     PG_HIP(c, hipGetLastError());
-    PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_ALIGN + 1], c->stream));
-    c->ev_valid[PG_K_ALIGN] = true;
+    if (U.timed) {
+        PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_ALIGN + 1], c->stream));
+        c->ev_valid[PG_K_ALIGN] = true;
+    }
     return PG_OK;
 }
 
@@ -478,6 +523,8 @@ int pg_ctx_destroy(pg_ctx* c) {
     c->d_g1.release(); c->d_g2.release(); c->d_gn.release(); c->d_gout.release();
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_block) if (e) (void)hipEventDestroy(e);
+    c->d_win.release();
+    if (c->h_win) (void)hipHostFree(c->h_win);
     if (c->h_active) (void)hipHostFree(c->h_active);
     if (c->h_status) (void)hipHostFree(c->h_status);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -773,10 +820,12 @@ int pg_align_launch(pg_ctx* c) {
     if (!c) return PG_ERR_INVALID;
     if (c->n_pairs == 0) return fail(c, PG_ERR_STATE, "no pairs uploaded");
     PG_HIP(c, hipSetDevice(c->device));
-    int rc = enqueue_align(c, c->work, c->d_pair_hap.p, c->d_pair_read.p, c->n_pairs,
+    int rc = enqueue_align(c, ctx_bufs(c, c->n_pairs), c->work, c->d_pair_hap.p, c->d_pair_read.p, c->n_pairs,
                            c->d_score.p, c->d_anchor.p, c->d_like.p);
     if (rc != PG_OK) return rc;
     c->launched = true;
+    c->n_results = c->n_pairs; c->r_score = c->d_score.p; c->r_anchor = c->d_anchor.p; c->r_like = c->d_like.p;
+    c->r_status = c->work.status;
     return PG_OK;
 }
 
@@ -791,10 +840,10 @@ int pg_results_fetch_async(pg_ctx* c, int32_t* score, int32_t* anchor, double* l
     if (!c) return PG_ERR_INVALID;
     if (!c->launched) return fail(c, PG_ERR_STATE, "nothing launched");
     PG_HIP(c, hipSetDevice(c->device));
-    const size_t n = (size_t)c->n_pairs;
-    if (score) PG_HIP(c, hipMemcpyAsync(score, c->d_score.p, n * 4, hipMemcpyDeviceToHost, c->stream));
-    if (anchor) PG_HIP(c, hipMemcpyAsync(anchor, c->d_anchor.p, n * 4, hipMemcpyDeviceToHost, c->stream));
-    if (like) PG_HIP(c, hipMemcpyAsync(like, c->d_like.p, n * 8, hipMemcpyDeviceToHost, c->stream));
+    const size_t n = (size_t)c->n_results;
+    if (score) PG_HIP(c, hipMemcpyAsync(score, c->r_score, n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (anchor) PG_HIP(c, hipMemcpyAsync(anchor, c->r_anchor, n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (like) PG_HIP(c, hipMemcpyAsync(like, c->r_like, n * 8, hipMemcpyDeviceToHost, c->stream));
     return PG_OK;
 }
 
@@ -813,6 +862,189 @@ int pg_align_pairs(pg_ctx* c, int64_t np, const int32_t* hap_idx, const int32_t*
     rc = pg_align_launch(c);
     if (rc != PG_OK) return rc;
     return pg_results_fetch(c, score, anchor, like);
+}
+
+int pg_align_window(pg_ctx* c, int n_haps, const char* hap_seq, const int64_t* hap_off, const int32_t* start_pos,
+                    const int32_t* var_seq_len, int n_reads, const char* seq, const char* qual, const int64_t* off,
+                    const int32_t* pos, const int32_t* mapq, int32_t* score, int32_t* anchor, double* like) {
+    if (!c) return PG_ERR_INVALID;
+    if (n_haps < 0 || n_reads < 0 || (n_haps > 0 && (!hap_seq || !hap_off || !start_pos || !var_seq_len)) ||
+        (n_reads > 0 && (!seq || !qual || !off || !pos || !mapq)))
+        return fail(c, PG_ERR_INVALID, "pg_align_window: bad arguments");
+    c->n_haps = 0; c->n_reads = 0; c->n_pairs = 0; c->launched = false;      // whatever was uploaded is given up
+    if (n_haps == 0 || n_reads == 0) return PG_OK;
+    const int64_t np = (int64_t)n_haps * n_reads;
+    // ---- the window as the host sees it: the same checks, in the same order, as the upload calls make ----
+    const int pad = c->max_read_len + 64;
+    int max_hap_len = 0, n_vote = 0;
+    for (int i = 0; i < n_haps; ++i) {
+        const int64_t l = hap_off[i + 1] - hap_off[i];
+        if (l < 0 || l > (1 << 30)) return fail(c, PG_ERR_INVALID, "haplotype %d has length %lld", i, (long long)l);
+        if (var_seq_len[i] != 0 && l > PG_MAX_HASHED_HAP_LEN)
+            return fail(c, PG_ERR_UNSUPPORTED, "haplotype %d with indels is %lld long; the 7-mer anchoring takes < 16384", i, (long long)l);
+        if (var_seq_len[i] != 0 && l < 15)
+            return fail(c, PG_ERR_UNSUPPORTED, "haplotype %d with indels is only %lld long; at least 15 bases are needed", i, (long long)l);
+        max_hap_len = std::max(max_hap_len, (int)l);
+        n_vote += var_seq_len[i] != 0;
+    }
+    const int64_t hap_total = hap_off[n_haps] - hap_off[0], read_total = off[n_reads] - off[0];
+    if (read_total < n_reads)
+        return fail(c, PG_ERR_UNSUPPORTED, "%d reads in %lld bases: reads must hold 1..%d bases", n_reads, (long long)read_total, c->max_read_len);
+    int max_rlen = 0, min_rlen = 0x7fffffff;
+    for (int i = 0; i < n_reads; ++i) {
+        const int64_t l = off[i + 1] - off[i];
+        if (l < 1 || l > c->max_read_len)
+            return fail(c, PG_ERR_UNSUPPORTED, "read %d has length %lld; this context takes 1..%d", i, (long long)l, c->max_read_len);
+        max_rlen = std::max(max_rlen, (int)l); min_rlen = std::min(min_rlen, (int)l);
+    }
+    for (int i = 0; i < n_reads; ++i)
+        if (mapq[i] < 0 || mapq[i] > 255) return fail(c, PG_ERR_UNSUPPORTED, "read %d has mapping quality %d outside 0..255", i, mapq[i]);
+    const bool uniform = max_rlen == min_rlen;
+    // a window too large for one block, or one the table-free anchoring kernel does not take, goes the long way
+    const bool bits = c->vote_kernel >= 0 ? (c->vote_kernel == 1 && max_rlen <= 263) : max_rlen <= 263;
+    const int64_t x_hap = hap_total + (int64_t)n_haps * pad + 64, x_read = read_total + (int64_t)n_reads * 31 + 64;
+    if (np > (1 << 20) || (n_vote > 0 && !bits) || x_hap + x_read > (16 << 20)) {
+        int rc = pg_haps_upload(c, n_haps, hap_seq, hap_off, start_pos, var_seq_len);
+        if (rc == PG_OK) rc = pg_reads_upload(c, n_reads, seq, qual, off, pos, mapq);
+        if (rc == PG_OK) rc = pg_pairs_block(c, 0, n_haps, 0, n_reads);
+        if (rc == PG_OK) rc = pg_align_launch(c);
+        if (rc == PG_OK) rc = pg_results_fetch(c, score, anchor, like);
+        c->n_haps = 0; c->n_reads = 0; c->n_pairs = 0;     // the results stay (n_results)
+        return rc;
+    }
+    PG_HIP(c, hipSetDevice(c->device));
+    // ---- the block: what the host fills (up to `in_bytes`), what the kernels make, the results ----
+    size_t at = 0;
+    auto take = [&](size_t bytes) { const size_t o = at; at += (bytes + 15) & ~(size_t)15; return o; };
+    const int n_waves = wave_bound(uniform, max_rlen, np);
+    const size_t o_soff = take(8 * ((size_t)n_haps + 1)), o_doff = take(8 * ((size_t)n_haps + 1)), o_h2off = take(8 * ((size_t)n_haps + 1));
+    const size_t o_hlen = take(4 * (size_t)n_haps), o_hstart = take(4 * (size_t)n_haps), o_hvar = take(4 * (size_t)n_haps), o_hord = take(4 * (size_t)n_haps);
+    const size_t o_vh = take(sizeof(pg::VoteHap) * ((size_t)n_vote + 1)), o_hcnt = take(4 * ((size_t)n_vote + 1));
+    const size_t o_roff = take(8 * ((size_t)n_reads + 1)), o_xoff = take(8 * ((size_t)n_reads + 1)), o_r2off = take(8 * ((size_t)n_reads + 1));
+    const size_t o_rlen = take(4 * (size_t)n_reads), o_rpos = take(4 * (size_t)n_reads), o_rmq = take(4 * (size_t)n_reads);
+    const size_t o_status = take(4 * pg::ST_WORDS);
+    const size_t o_order = take(uniform ? 0 : 4 * (size_t)np), o_waves = take(uniform ? 0 : sizeof(pg::WaveDesc) * ((size_t)n_waves + 1));
+    const size_t o_hraw = take((size_t)hap_total + 16), o_rseq = take((size_t)read_total + 64), o_rqual = take((size_t)read_total + 64);
+    const size_t in_bytes = at;
+    // row offsets (the same as pg_haps_upload and k_read_meta make)
+    std::vector<int64_t>& h2 = c->win_tmp;
+    h2.assign((size_t)n_haps + n_reads + 2, 0);
+    int64_t* hap2off = h2.data(); int64_t* read2off = h2.data() + n_haps + 1;
+    for (int i = 0; i < n_haps; ++i) hap2off[i + 1] = hap2off[i] + ((hap_off[i + 1] - hap_off[i]) + 15) / 16 + 2;
+    int64_t xo = 0;
+    for (int i = 0; i < n_reads; ++i) read2off[i + 1] = read2off[i] + ((off[i + 1] - off[i]) + 15) / 16 + 2;
+    const size_t o_hapx = take(2 * (size_t)x_hap), o_hap2 = take(4 * ((size_t)hap2off[n_haps] + 16)), o_hapU = take(4 * ((size_t)hap2off[n_haps] + 16));
+    const size_t o_ubits = take(4 * (size_t)(n_vote + 1) * (pg::kHashSize / 32));
+    const size_t o_readx = take(2 * (size_t)x_read), o_read2 = take(4 * ((size_t)read2off[n_reads] + 16));
+    const size_t o_ph = take(4 * (size_t)np), o_pr = take(4 * (size_t)np), o_recs = take(sizeof(pg::VoteRec) * ((size_t)n_vote * n_reads + 1));
+    const size_t o_ain = take(4 * (size_t)np);
+    const size_t o_res = at;
+    const size_t o_score = take(4 * (size_t)np), o_anchor = take(4 * (size_t)np), o_like = take(8 * (size_t)np), o_flags = take(64);
+    const size_t res_bytes = at - o_res, total_bytes = at;
+    if (c->h_win_cap < in_bytes + res_bytes) {
+        if (c->h_win) { PG_HIP(c, hipHostFree(c->h_win)); c->h_win = nullptr; c->h_win_cap = 0; }
+        const size_t want = (in_bytes + res_bytes) * 2 + 4096;
+        PG_HIP(c, hipHostMalloc((void**)&c->h_win, want, hipHostMallocDefault));
+        c->h_win_cap = want;
+    }
+    PG_HIP(c, c->d_win.reserve(total_bytes + 256));
+    uint8_t* H = c->h_win;
+    uint8_t* D = c->d_win.p;
+    {
+        int64_t* soff = (int64_t*)(H + o_soff); int64_t* doff = (int64_t*)(H + o_doff); int64_t* h2o = (int64_t*)(H + o_h2off);
+        int32_t* hlen = (int32_t*)(H + o_hlen); int32_t* hst = (int32_t*)(H + o_hstart); int32_t* hvar = (int32_t*)(H + o_hvar);
+        int32_t* hord = (int32_t*)(H + o_hord); pg::VoteHap* vh = (pg::VoteHap*)(H + o_vh); int32_t* hcnt = (int32_t*)(H + o_hcnt);
+        int nv = 0;
+        for (int i = 0; i < n_haps; ++i) {
+            soff[i] = hap_off[i] - hap_off[0];
+            doff[i] = soff[i] + (int64_t)i * pad;
+            h2o[i] = hap2off[i];
+            hlen[i] = (int32_t)(hap_off[i + 1] - hap_off[i]);
+            hst[i] = start_pos[i]; hvar[i] = var_seq_len[i];
+            hord[i] = var_seq_len[i] != 0 ? nv : -1;
+            if (var_seq_len[i] != 0) { vh[nv] = pg::VoteHap{i, hlen[i], hap2off[i]}; hcnt[nv] = nv * n_reads; ++nv; }
+        }
+        soff[n_haps] = hap_total; doff[n_haps] = hap_total + (int64_t)n_haps * pad; h2o[n_haps] = hap2off[n_haps];
+        hcnt[nv] = nv * n_reads;
+        int64_t* roff = (int64_t*)(H + o_roff); int64_t* xoff = (int64_t*)(H + o_xoff); int64_t* r2o = (int64_t*)(H + o_r2off);
+        int32_t* rlen = (int32_t*)(H + o_rlen);
+        for (int i = 0; i < n_reads; ++i) {
+            const int len = (int)(off[i + 1] - off[i]);
+            roff[i] = off[i] - off[0]; xoff[i] = xo; r2o[i] = read2off[i]; rlen[i] = len;
+            xo += ((len + 7) / 8) * 8 + 24;
+        }
+        roff[n_reads] = read_total; xoff[n_reads] = xo; r2o[n_reads] = read2off[n_reads];
+        std::memcpy(H + o_rpos, pos, 4 * (size_t)n_reads);
+        std::memcpy(H + o_rmq, mapq, 4 * (size_t)n_reads);
+        int32_t* st = (int32_t*)(H + o_status);
+        std::memset(st, 0, 4 * pg::ST_WORDS);
+        st[pg::ST_BAD_PAIR] = 0x7fffffff; st[pg::ST_N_VOTE] = nv * n_reads;
+        if (!uniform) {
+            // slots grouped by read length, wavefronts of up to 64 slots of one length; a pair is haplotype * n_reads + read
+            std::vector<int32_t>& by_len = c->win_tmp32;
+            by_len.assign((size_t)max_rlen + 2, 0);
+            for (int i = 0; i < n_reads; ++i) ++by_len[rlen[i] + 1];
+            int32_t* order = (int32_t*)(H + o_order); pg::WaveDesc* waves = (pg::WaveDesc*)(H + o_waves);
+            int nw = 0; int64_t slot = 0;
+            for (int L = 0; L <= max_rlen; ++L) {             // by_len[L + 1] reads of length L: n_haps pairs each
+                const int64_t cnt = (int64_t)by_len[L + 1] * n_haps;
+                for (int64_t k = 0; k < cnt; k += 64) waves[nw++] = pg::WaveDesc{(int32_t)(slot + k), (int32_t)std::min<int64_t>(64, cnt - k), L, 0};
+                by_len[L + 1] = (int32_t)slot;               // from here on: next free slot of the length
+                slot += cnt;
+            }
+            for (int h = 0; h < n_haps; ++h)
+                for (int r = 0; r < n_reads; ++r) order[by_len[rlen[r] + 1]++] = h * n_reads + r;
+            st[pg::ST_N_WAVES] = nw;
+        }
+        std::memcpy(H + o_hraw, hap_seq + hap_off[0], (size_t)hap_total);
+        std::memcpy(H + o_rseq, seq + off[0], (size_t)read_total);
+        std::memcpy(H + o_rqual, qual + off[0], (size_t)read_total);
+    }
+    if (x_read < xo + 64) return fail(c, PG_ERR_HIP, "pg_align_window: element rows larger than their bound");
+    PG_HIP(c, hipMemcpyAsync(D, H, in_bytes, hipMemcpyHostToDevice, c->stream));
+    PG_HIP(c, hipMemsetAsync(D + o_flags, 0, 64, c->stream));
+    pg::WindowArgs A;
+    A.n_haps = n_haps; A.n_reads = n_reads; A.n_vote_haps = n_vote; A.pad = pad; A.cap = (int)c->table.size() - 1;
+    A.hap_raw = D + o_hraw; A.hap_soff = (const int64_t*)(D + o_soff); A.hap_doff = (const int64_t*)(D + o_doff);
+    A.hap2off = (const int64_t*)(D + o_h2off); A.hap_vote_ord = (const int32_t*)(D + o_hord);
+    A.rseq = D + o_rseq; A.rqual = D + o_rqual; A.roff = (const int64_t*)(D + o_roff); A.read_xoff = (const int64_t*)(D + o_xoff);
+    A.read2off = (const int64_t*)(D + o_r2off); A.read_len = (const int32_t*)(D + o_rlen); A.codes = c->d_codes.p;
+    A.hapx = (uint16_t*)(D + o_hapx); A.hap2 = (uint32_t*)(D + o_hap2); A.hapU = (uint32_t*)(D + o_hapU); A.hapUbits = (uint32_t*)(D + o_ubits);
+    A.readx = (uint16_t*)(D + o_readx); A.read2 = (uint32_t*)(D + o_read2);
+    A.pair_hap = (int32_t*)(D + o_ph); A.pair_read = (int32_t*)(D + o_pr); A.recs = (pg::VoteRec*)(D + o_recs);
+    A.flags = (int32_t*)(D + o_flags);
+    const int pair_blocks = (int)std::min<int64_t>((np + 255) / 256, 1024);
+    hipLaunchKernelGGL(pg::k_window_pack, dim3((unsigned)(n_haps + (n_reads + 3) / 4 + pair_blocks)), dim3(256), 0, c->stream, A);
+    PG_HIP(c, hipGetLastError());
+    AlignBufs U;
+    U.hapx = A.hapx; U.hap_doff = A.hap_doff; U.hap_len = (const int32_t*)(D + o_hlen); U.hap_start = (const int32_t*)(D + o_hstart);
+    U.hap_varlen = (const int32_t*)(D + o_hvar); U.hap2 = A.hap2; U.hapU = A.hapU; U.hapUbits = A.hapUbits;
+    U.vh = (const pg::VoteHap*)(D + o_vh);
+    U.readx = A.readx; U.read_xoff = A.read_xoff; U.read2 = A.read2; U.read_pos = (const int32_t*)(D + o_rpos);
+    U.read_mapq = (const int32_t*)(D + o_rmq);
+    U.n_vote_haps = n_vote; U.max_rlen = max_rlen; U.max_hap_len = max_hap_len; U.uniform = uniform; U.n_waves = n_waves;
+    U.timed = false;
+    pg::PairWork W{};
+    W.status = (int32_t*)(D + o_status); W.hap_cnt = (int32_t*)(D + o_hcnt);
+    W.order = uniform ? nullptr : (int32_t*)(D + o_order); W.waves = uniform ? nullptr : (pg::WaveDesc*)(D + o_waves);
+    W.recs = A.recs; W.anchor_in = (int32_t*)(D + o_ain);
+    int rc = enqueue_align(c, U, W, A.pair_hap, A.pair_read, np, (int32_t*)(D + o_score), (int32_t*)(D + o_anchor), (double*)(D + o_like));
+    if (rc != PG_OK) { (void)hipStreamSynchronize(c->stream); return rc; }
+    uint8_t* R = H + in_bytes;                            // the results' place in the host block
+    PG_HIP(c, hipMemcpyAsync(R, D + o_res, res_bytes, hipMemcpyDeviceToHost, c->stream));
+    PG_HIP(c, hipStreamSynchronize(c->stream));
+    const int32_t flags = *(const int32_t*)(R + (o_flags - o_res));
+    if (flags & 1) return fail(c, PG_ERR_UNSUPPORTED, "a base quality above 127 was found");
+    if (flags & 2) return fail(c, PG_ERR_UNSUPPORTED, "a haplotype or a read holds a byte outside 1..31, 33..126");
+    if (score) std::memcpy(score, R + (o_score - o_res), 4 * (size_t)np);
+    if (anchor) std::memcpy(anchor, R + (o_anchor - o_res), 4 * (size_t)np);
+    if (like) std::memcpy(like, R + (o_like - o_res), 8 * (size_t)np);
+    // the results stay on the device for pg_genotype_loglik, the caller stage and pg_results_fetch, as after pg_align_launch
+    c->launched = true;
+    c->n_results = np; c->r_score = (const int32_t*)(D + o_score); c->r_anchor = (const int32_t*)(D + o_anchor);
+    c->r_like = (const double*)(D + o_like); c->r_status = (const int32_t*)(D + o_status);
+    c->ev_valid[PG_K_ANCHOR] = c->ev_valid[PG_K_ALIGN] = false;      // this call's kernels are not timed
+    return PG_OK;
 }
 
 int pg_align_pairs_noalloc(pg_ctx* c, int64_t np, const int32_t* d_hap_idx, const int32_t* d_read_idx,
@@ -847,7 +1079,7 @@ int pg_align_pairs_noalloc(pg_ctx* c, int64_t np, const int32_t* d_hap_idx, cons
     // rewrites the status words; every other array is written before it is read
     int rc = enqueue_prep(c, W, d_hap_idx, d_read_idx, np);
     if (rc != PG_OK) return rc;
-    rc = enqueue_align(c, W, d_hap_idx, d_read_idx, np, d_score, d_anchor, d_like);
+    rc = enqueue_align(c, ctx_bufs(c, np), W, d_hap_idx, d_read_idx, np, d_score, d_anchor, d_like);
     if (rc != PG_OK) return rc;
     PG_HIP(c, hipMemcpyAsync(c->h_status, W.status, pg::ST_WORDS * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     PG_HIP(c, hipStreamSynchronize(c->stream));
@@ -861,7 +1093,7 @@ int pg_anchor_stats(pg_ctx* c, int64_t* counts) {
     if (!c || !counts) return PG_ERR_INVALID;
     if (!c->launched) return fail(c, PG_ERR_STATE, "nothing launched");
     PG_HIP(c, hipSetDevice(c->device));
-    PG_HIP(c, hipMemcpyAsync(c->h_status, c->work.status, pg::ST_WORDS * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    PG_HIP(c, hipMemcpyAsync(c->h_status, c->r_status, pg::ST_WORDS * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     PG_HIP(c, hipStreamSynchronize(c->stream));
     counts[0] = c->h_status[pg::ST_N_VOTE];
     counts[1] = c->h_status[pg::ST_N_NAMED];
@@ -886,7 +1118,7 @@ int pg_genotype_loglik(pg_ctx* c, int64_t ng, const int64_t* b1, const int64_t* 
     if (!c->launched) return fail(c, PG_ERR_STATE, "no likelihoods on the device: launch an alignment first");
     if (ng == 0) return PG_OK;
     for (int64_t g = 0; g < ng; ++g)
-        if (nreads[g] < 0 || b1[g] < 0 || b2[g] < 0 || b1[g] + nreads[g] > c->n_pairs || b2[g] + nreads[g] > c->n_pairs)
+        if (nreads[g] < 0 || b1[g] < 0 || b2[g] < 0 || b1[g] + nreads[g] > c->n_results || b2[g] + nreads[g] > c->n_results)
             return fail(c, PG_ERR_INVALID, "genotype row %lld reaches outside the pair list", (long long)g);
     PG_HIP(c, hipSetDevice(c->device));
     PG_HIP(c, c->d_g1.reserve(ng)); PG_HIP(c, c->d_g2.reserve(ng));
@@ -896,7 +1128,7 @@ int pg_genotype_loglik(pg_ctx* c, int64_t ng, const int64_t* b1, const int64_t* 
     PG_HIP(c, hipMemcpyAsync(c->d_gn.p, nreads, ng * 4, hipMemcpyHostToDevice, c->stream));
     PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_GENOTYPE], c->stream));
     hipLaunchKernelGGL(pg::k_genotype, dim3((unsigned)((ng * 64 + 255) / 256)), dim3(256), 0, c->stream,
-                       c->d_like.p, c->d_g1.p, c->d_g2.p, c->d_gn.p, c->d_gout.p, ng);
+                       c->r_like, c->d_g1.p, c->d_g2.p, c->d_gn.p, c->d_gout.p, ng);
     PG_HIP(c, hipGetLastError());
     PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_GENOTYPE + 1], c->stream));
     c->ev_valid[PG_K_GENOTYPE] = true;
@@ -996,7 +1228,7 @@ int pg_windows_upload(pg_ctx* c, int nw, const int32_t* n_haps, const int32_t* n
         const int nr = o[ni];
         if (nr == 0)
             return fail(c, PG_ERR_UNSUPPORTED, "window %d has no reads (the reference divides by zero, cpopulation.pyx:883)", w);
-        if (like_base[w] < 0 || like_base[w] + (int64_t)nh * nr > c->n_pairs)
+        if (like_base[w] < 0 || like_base[w] + (int64_t)nh * nr > (c->launched ? c->n_results : c->n_pairs))
             return fail(c, PG_ERR_INVALID, "window %d reaches outside the pair list", w);
         pg::WinDesc& W = wins[w];
         W.n_hap = nh; W.n_ind = ni; W.n_reads = nr; W.n_gen = nh * (nh + 1) / 2;
@@ -1036,7 +1268,7 @@ int pg_caller_launch(pg_ctx* c, int max_iters) {
     if (!c->launched) return fail(c, PG_ERR_STATE, "no likelihoods on the device: launch an alignment first");
     if (c->n_windows == 0) return fail(c, PG_ERR_STATE, "no windows uploaded");
     for (const pg::WinDesc& W : c->h_wins)
-        if (W.like_base + (int64_t)W.n_hap * W.n_reads > c->n_pairs)
+        if (W.like_base + (int64_t)W.n_hap * W.n_reads > c->n_results)
             return fail(c, PG_ERR_STATE, "the windows do not fit the current pair list");
     PG_HIP(c, hipSetDevice(c->device));
     PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_CALLER_SETUP], c->stream));
@@ -1049,10 +1281,10 @@ int pg_caller_launch(pg_ctx* c, int max_iters) {
         PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_gl_tile), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)(lds_doubles * sizeof(double))));
         hipLaunchKernelGGL(pg::k_gl_tile, dim3((unsigned)c->win_inds_total), dim3(256), lds_doubles * sizeof(double), c->stream,
-                           c->d_wins.p, c->n_windows, c->d_ioff.p, c->d_like.p, c->d_cells.p, c->d_win_max.p, lds_doubles);
+                           c->d_wins.p, c->n_windows, c->d_ioff.p, c->r_like, c->d_cells.p, c->d_win_max.p, lds_doubles);
     } else {
         hipLaunchKernelGGL(pg::k_gl, dim3((unsigned)((c->win_cells + 255) / 256)), dim3(256), 0, c->stream,
-                           c->d_wins.p, c->n_windows, c->d_ioff.p, c->d_like.p, c->d_cells.p, c->d_win_max.p, c->win_cells);
+                           c->d_wins.p, c->n_windows, c->d_ioff.p, c->r_like, c->d_cells.p, c->d_win_max.p, c->win_cells);
     }
     PG_HIP(c, hipGetLastError());
     if (tile) {

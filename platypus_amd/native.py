@@ -17,7 +17,7 @@ PG_OK = 0
 PG_ERR_NO_DEVICE, PG_ERR_INVALID, PG_ERR_HIP, PG_ERR_UNSUPPORTED, PG_ERR_STATE = -1, -2, -3, -4, -5
 PG_SCORE_ASSERT_FAILED = -1
 PG_K_ANCHOR, PG_K_ALIGN, PG_K_GENOTYPE, PG_K_CALLER_SETUP, PG_K_CALLER_EM = 0, 1, 2, 3, 4
-ABI_VERSION = 5
+ABI_VERSION = 6
 NOALLOC_MAX_PAIRS, NOALLOC_MAX_INDEL_HAPS = 262144, 65536      # PG_NOALLOC_MAX_* of include/platgpu.h
 
 # every symbol include/platgpu.h declares: (restype, argtypes)
@@ -42,6 +42,8 @@ SYMBOLS = {
     "pg_results_fetch": (C.c_int, [C.c_void_p, _i32p, _i32p, _f64p]),
     "pg_results_fetch_async": (C.c_int, [C.c_void_p, _i32p, _i32p, _f64p]),
     "pg_align_pairs": (C.c_int, [C.c_void_p, C.c_int64, _i32p, _i32p, _i32p, _i32p, _f64p]),
+    "pg_align_window": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _i64p, _i32p, _i32p, C.c_int, C.c_void_p, C.c_void_p, _i64p,
+                                  _i32p, _i32p, _i32p, _i32p, _f64p]),
     "pg_align_pairs_noalloc": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pg_kernel_time_ms": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
     "pg_anchor_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
@@ -211,6 +213,21 @@ class AlignContext(object):
             return z, z.copy(), np.empty(0, dtype=np.float64)
         self.launch()
         return self.fetch()
+
+    def align_window(self, hap_seq, hap_off, hap_start, hap_varlen, read_seq, read_qual, read_off, read_pos, read_mapq,
+                     likelihood=True):
+        """every haplotype against every read in one call (pair h * n_reads + r); see include/platgpu.h"""
+        hs = _arr(hap_seq, np.uint8); ho = _arr(hap_off, np.int64); sp = _arr(hap_start, np.int32); vl = _arr(hap_varlen, np.int32)
+        rs = _arr(read_seq, np.uint8); rq = _arr(read_qual, np.uint8); ro = _arr(read_off, np.int64)
+        rp = _arr(read_pos, np.int32); mq = _arr(read_mapq, np.int32)
+        nh, nr = len(ho) - 1, len(ro) - 1
+        n = nh * nr
+        score = np.empty(n, dtype=np.int32); anchor = np.empty(n, dtype=np.int32)
+        like = np.empty(n, dtype=np.float64) if likelihood else None
+        self._check(LIB.pg_align_window(self._h, nh, _ptr(hs), _ptr(ho), _ptr(sp), _ptr(vl), nr, _ptr(rs), _ptr(rq), _ptr(ro),
+                                        _ptr(rp), _ptr(mq), _ptr(score), _ptr(anchor), _ptr(like)))
+        self.n_pairs = n                      # the results stay on the device (fetch, genotype_loglik, the caller stage)
+        return score, anchor, like
 
     def align_pairs_noalloc(self, n_pairs, d_hap_idx, d_read_idx, d_score, d_anchor, d_like):
         """device addresses (integers) of the caller's arrays; see include/platgpu.h"""

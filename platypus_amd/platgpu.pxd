@@ -26,6 +26,10 @@ cdef extern from "platgpu.h":
     int pg_align_launch(pg_ctx* ctx)
     int pg_sync(pg_ctx* ctx)
     int pg_results_fetch(pg_ctx* ctx, int32_t* score, int32_t* anchor, double* likelihood)
+    int pg_align_window(pg_ctx* ctx, int n_haps, const char* hap_seq, const int64_t* hap_off, const int32_t* hap_start_pos,
+                        const int32_t* hap_var_seq_len, int n_reads, const char* read_seq, const char* read_qual,
+                        const int64_t* read_off, const int32_t* read_pos, const int32_t* read_mapq,
+                        int32_t* score, int32_t* anchor, double* likelihood)
     int pg_genotype_loglik(pg_ctx* ctx, int64_t n_gen, const int64_t* pair_base1, const int64_t* pair_base2,
                            const int32_t* n_reads, double* out)
     int pg_windows_upload(pg_ctx* ctx, int n_windows, const int32_t* n_haps, const int32_t* n_inds,

@@ -86,6 +86,21 @@ def main():
     # (4) the same windows as one batch through the ABI (upload + launch + fetch)
     ctx = native.AlignContext(0)
     try:
+        def win(w):
+            h0, r0 = w * H, w * R
+            return (b["hap_seq"], b["hap_off"][h0:h0 + H + 1], b["hap_start"][h0:h0 + H], b["hap_varlen"][h0:h0 + H],
+                    b["read_seq"], b["read_qual"], b["read_off"][r0:r0 + R + 1], b["read_pos"][r0:r0 + R], b["read_mapq"][r0:r0 + R])
+        for which, name in ((0, "pg_align_window, one window per call"), (1, "the five upload/launch/fetch calls per window")):
+            times = []
+            for w in list(range(min(W, 20))) + list(range(W)):
+                a = win(w)
+                t0 = time.perf_counter()
+                if which == 0:
+                    ctx.align_window(*a)
+                else:
+                    ctx.upload_haps(*a[:4]); ctx.upload_reads(*a[4:]); ctx.pairs_block(0, H, 0, R); ctx.launch(); ctx.fetch()
+                times.append(time.perf_counter() - t0)
+            report(name, times[min(W, 20):], H * R)
         times = []
         for _ in range(5):
             t0 = time.perf_counter()
