@@ -15,7 +15,7 @@ SRC_DIR = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libplatgpu.so")
 SOURCES = ["platgpu.hip"]
-DEPS = ["platgpu.hip", "pg_kernels.hip.h", "pg_align.hip.h", "pg_prep.hip.h", "pg_caller.hip.h", "pg_inflate.hip.h", "pg_window.hip.h", os.path.join(ROOT, "include", "platgpu.h")]
+DEPS = ["platgpu.hip", "pg_kernels.hip.h", "pg_align.hip.h", "pg_prep.hip.h", "pg_caller.hip.h", "pg_inflate.hip.h", "pg_window.hip.h", "pg_band.hip.h", os.path.join(ROOT, "include", "platgpu.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sdwa-peephole=false",
          "-Wall", "-Wno-unused-function"]

@@ -21,6 +21,7 @@
 #include "pg_prep.hip.h"
 #include "pg_caller.hip.h"
 #include "pg_inflate.hip.h"
+#include "pg_band.hip.h"
 #include "pg_window.hip.h"
 
 namespace {
@@ -65,6 +66,7 @@ constexpr size_t kNaOffRecs = kNaOffWaves + up256(kNaWaves * sizeof(pg::WaveDesc
 constexpr size_t kNaOffAnchor = kNaOffRecs + up256(kNaPairs * sizeof(pg::VoteRec));
 constexpr size_t kNaBytes = kNaOffAnchor + up256(kNaPairs * 4);
 constexpr int kMaxDevices = 64;
+constexpr int64_t kBandMaxPairs = 16384;                            // launches up to this size take k_align_band
 }  // namespace
 
 static __device__ __align__(256) unsigned char scratch[kNaBytes];
@@ -107,6 +109,7 @@ struct pg_ctx {
     DevBuf<pg::SeqCodes> d_codes;        // code tables of the sequence bytes (pg_align.hip.h)
     // kernel-choice overrides of pg_set_option (tests and measurements); 0 / -1 = the library decides
     int vote_waves = 0;                  // "vote_waves": wavefronts per workgroup of the vote kernel
+    int align_kernel = -1;               // "align_kernel": 0 one lane per pair (k_align2), 1 eight lanes per pair (k_align_band)
     int vote5_lds = 0;                   // dynamic LDS k_vote5 has been allowed so far
     int vote_kernel = -1;                // "vote_kernel": 0 position table in LDS (k_vote4), 1 bit-parallel counts (k_vote5)
     int lds_pad = 0;                     // "align_lds_pad": extra LDS per workgroup of the DP kernel, lowers its occupancy
@@ -280,6 +283,7 @@ struct AlignBufs {
     const uint16_t* hapx; const int64_t* hap_doff; const int32_t* hap_len; const int32_t* hap_start; const int32_t* hap_varlen;
     const uint32_t* hap2; const uint32_t* hapU; const uint32_t* hapUbits; const pg::VoteHap* vh;
     const uint16_t* readx; const int64_t* read_xoff; const uint32_t* read2; const int32_t* read_pos; const int32_t* read_mapq;
+    const int32_t* read_len;
     int n_vote_haps, max_rlen, max_hap_len;
     bool uniform;
     int n_waves;          // wavefronts of the alignment kernel (ragged: an upper bound, the count is in the status words)
@@ -291,7 +295,7 @@ AlignBufs ctx_bufs(const pg_ctx* c, int64_t np) {
     B.hapx = c->d_hapx.p; B.hap_doff = c->d_hap_doff.p; B.hap_len = c->d_hap_len.p; B.hap_start = c->d_hap_start.p;
     B.hap_varlen = c->d_hap_varlen.p; B.hap2 = c->d_hap2.p; B.hapU = c->d_hapU.p; B.hapUbits = c->d_hapUbits.p; B.vh = c->d_vh.p;
     B.readx = c->d_readx.p; B.read_xoff = c->d_read_xoff.p; B.read2 = c->d_read2.p; B.read_pos = c->d_read_pos.p;
-    B.read_mapq = c->d_read_mapq.p;
+    B.read_mapq = c->d_read_mapq.p; B.read_len = c->d_read_len.p;
     B.n_vote_haps = c->n_vote_haps; B.max_rlen = c->max_rlen; B.max_hap_len = c->max_hap_len; B.uniform = c->uniform_rlen;
     B.n_waves = wave_bound(c, np);
     B.timed = true;
@@ -418,7 +422,15 @@ int enqueue_align(pg_ctx* c, const AlignBufs& U, const pg::PairWork& W, const in
     if (c->lds_pad > 0)
         PG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pg::k_align2), hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_pad));
     if (U.timed) PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_ALIGN], c->stream));
-    hipLaunchKernelGGL(pg::k_align2, dim3((n_waves + 3) / 4), dim3(256), c->lds_pad, c->stream, B);
+    // A launch of few pairs goes to the kernel with eight lanes per pair: its wavefronts finish in a fifth of the time
+    // a lone wavefront of k_align2 takes, and there are eight times as many of them to spread over the CUs; from some
+    // tens of thousands of pairs on k_align2's wavefronts fill the machine and do the same work in half the instructions.
+    const bool band = c->align_kernel >= 0 ? c->align_kernel == 1 : np <= kBandMaxPairs;
+    if (band) {
+        hipLaunchKernelGGL(pg::k_align_band, dim3((unsigned)((np + 7) / 8)), dim3(64), 0, c->stream, B, U.read_len);
+    } else {
+        hipLaunchKernelGGL(pg::k_align2, dim3((n_waves + 3) / 4), dim3(256), c->lds_pad, c->stream, B);
+    }
     PG_HIP(c, hipGetLastError());
     if (U.timed) {
         PG_HIP(c, hipEventRecord(c->ev[2 * PG_K_ALIGN + 1], c->stream));
@@ -591,6 +603,9 @@ int pg_set_option(pg_ctx* c, const char* name, const char* value) {
     } else if (n == "vote_kernel") {
         if (dflt) c->vote_kernel = -1; else if (v == "table") c->vote_kernel = 0; else if (v == "bits") c->vote_kernel = 1;
         else return fail(c, PG_ERR_INVALID, "vote_kernel: table, bits or default");
+    } else if (n == "align_kernel") {
+        if (dflt) c->align_kernel = -1; else if (v == "lane") c->align_kernel = 0; else if (v == "band") c->align_kernel = 1;
+        else return fail(c, PG_ERR_INVALID, "align_kernel: lane, band or default");
     } else if (n == "align_lds_pad") {
         c->lds_pad = dflt ? 0 : std::max(0, std::min(159 * 1024, std::atoi(value)));
     } else {
@@ -1021,7 +1036,7 @@ int pg_align_window(pg_ctx* c, int n_haps, const char* hap_seq, const int64_t* h
     U.hap_varlen = (const int32_t*)(D + o_hvar); U.hap2 = A.hap2; U.hapU = A.hapU; U.hapUbits = A.hapUbits;
     U.vh = (const pg::VoteHap*)(D + o_vh);
     U.readx = A.readx; U.read_xoff = A.read_xoff; U.read2 = A.read2; U.read_pos = (const int32_t*)(D + o_rpos);
-    U.read_mapq = (const int32_t*)(D + o_rmq);
+    U.read_mapq = (const int32_t*)(D + o_rmq); U.read_len = (const int32_t*)(D + o_rlen);
     U.n_vote_haps = n_vote; U.max_rlen = max_rlen; U.max_hap_len = max_hap_len; U.uniform = uniform; U.n_waves = n_waves;
     U.timed = false;
     pg::PairWork W{};

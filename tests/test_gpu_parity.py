@@ -106,6 +106,33 @@ def test_both_anchoring_kernels(kernel, kw):
         c.close()
 
 
+@pytest.mark.parametrize("kernel", ["lane", "band"])
+@pytest.mark.parametrize("kw", [
+    dict(n_windows=40, read_len=150, seed=71),
+    dict(n_windows=30, read_len=100, indel_hap_frac=0.6, homopolymers=True, n_frac=0.01, seed=72),
+    dict(n_windows=25, read_len=120, ragged=True, indel_hap_frac=0.5, seed=73),
+    dict(n_windows=20, read_len=36, hap_len=300, haps_per_window=7, reads_per_window=50, ragged=True, seed=74),
+    dict(n_windows=6, read_len=700, hap_len=2500, reads_per_window=20, indel_hap_frac=0.5, homopolymers=True, seed=75),
+    dict(n_windows=150, read_len=151, haps_per_window=5, reads_per_window=33, sub_rate=0.05, read_indel_frac=0.4, seed=76),
+])
+def test_both_alignment_kernels(kernel, kw):
+    """the banded DP with one lane per pair (large launches) and with eight lanes per pair (small launches): the
+    reference's scores from either, whatever the launch size"""
+    from platypus_amd import native, synth
+    c = native.AlignContext(0, 1024)
+    try:
+        c.set_option("align_kernel", kernel)
+        b = synth.make_batch(**kw)
+        rng = np.random.default_rng(kw["seed"])
+        nR = len(b["read_pos"])
+        shift = np.where(rng.random(nR) < 0.15, rng.integers(-40, 41, nR), 0)
+        shift = np.where(rng.random(nR) < 0.03, rng.integers(-kw.get("hap_len", 750), kw.get("hap_len", 750), nR), shift)
+        b["read_pos"] = (b["read_pos"].astype(np.int64) + shift).astype(np.int32)
+        _check_batch(c, b)
+    finally:
+        c.close()
+
+
 def test_edge_cases(ctx):
     """Short reads, reads running off the haplotype end on both paths, a
     haplotype shorter than a 7-mer, repeated 7-mers only, no votes."""
