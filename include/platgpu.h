@@ -238,8 +238,9 @@ int pg_align_window(pg_ctx *ctx, int n_haps, const char *hap_seq, const int64_t 
  *     batch; more is refused with PG_ERR_UNSUPPORTED.
  * The call returns after the results are complete (it waits for the context's
  * stream).  All contexts of a GPU share that GPU's array: two calls that overlap
- * on one GPU (two host threads, two contexts) race and must be serialised by the
- * caller.  The results of pg_align_launch and the pair list of pg_pairs_upload
+ * on one GPU (two host threads, two contexts) would race on it, so the second
+ * one is refused with PG_ERR_STATE and writes nothing; the caller serialises
+ * them or tries again.  The results of pg_align_launch and the pair list of pg_pairs_upload
  * are left untouched.  An index outside the uploaded batches gives
  * PG_ERR_INVALID and no output is written.
  */

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -74,6 +75,13 @@ static __device__ __align__(256) unsigned char scratch[kNaBytes];
 namespace {
 std::mutex g_scratch_mutex;
 unsigned char* g_scratch_ptr[kMaxDevices] = {};
+std::atomic<int> g_scratch_busy[kMaxDevices];      // 1 while a call is using the device's array
+
+struct ScratchHold {                                // the device's array for the length of a call; `got` says whether it was free
+    int device; bool got;
+    explicit ScratchHold(int d) : device(d), got(g_scratch_busy[d].exchange(1) == 0) {}
+    ~ScratchHold() { if (got) g_scratch_busy[device].store(0); }
+};
 
 // Device address of `scratch` on `device`, which must be the current device.  Every GPU holds its
 // own copy of the array at its own address.
@@ -1078,6 +1086,9 @@ int pg_align_pairs_noalloc(pg_ctx* c, int64_t np, const int32_t* d_hap_idx, cons
     if ((size_t)c->max_rlen + 2 > kNaLen)
         return fail(c, PG_ERR_UNSUPPORTED, "pg_align_pairs_noalloc: reads of %d bases", c->max_rlen);
     if (np == 0) return PG_OK;
+    ScratchHold hold(c->device);
+    if (!hold.got)
+        return fail(c, PG_ERR_STATE, "pg_align_pairs_noalloc: another call is using the fixed device array of GPU %d", c->device);
     PG_HIP(c, hipSetDevice(c->device));
     unsigned char* base = c->scratch_ptr;              // never the array's name: that is no device address on the host
     pg::PairWork W;

@@ -56,3 +56,13 @@ class DeviceArray(object):
             self.free()
         except Exception:
             pass
+
+
+_hip.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+
+
+def free_bytes():
+    """free device memory of the current device, as the runtime reports it"""
+    free, total = C.c_size_t(0), C.c_size_t(0)
+    _ok(_hip.hipMemGetInfo(C.byref(free), C.byref(total)), "hipMemGetInfo")
+    return free.value

@@ -109,3 +109,87 @@ def test_noalloc_at_its_largest_size():
         _same(_noalloc(ctx, ph[:777], pr[:777]), [x[:777] for x in want])
     finally:
         ctx.close()
+
+
+def test_noalloc_takes_no_device_memory():
+    """free device memory as the runtime reports it is the same before and after a call (the first call of a process
+    may load code objects, so one call is made before the measurement)"""
+    from platypus_amd import native, synth
+    from tests.hipmem import DeviceArray, free_bytes
+    b = synth.make_batch(n_windows=300, haps_per_window=5, reads_per_window=40, read_len=120, hap_len=500,
+                         indel_hap_frac=0.6, ragged=True, seed=77)
+    ctx = native.AlignContext(0)
+    try:
+        ctx.upload_haps(b["hap_seq"], b["hap_off"], b["hap_start"], b["hap_varlen"])
+        ctx.upload_reads(b["read_seq"], b["read_qual"], b["read_off"], b["read_pos"], b["read_mapq"])
+        n = len(b["pair_hap"])
+        d = [DeviceArray(n, np.int32, b["pair_hap"]), DeviceArray(n, np.int32, b["pair_read"]),
+             DeviceArray(n, np.int32), DeviceArray(n, np.int32), DeviceArray(n, np.float64)]
+        try:
+            ctx.align_pairs_noalloc(1000, *[x.ptr for x in d])          # a small launch (eight lanes per pair) ...
+            ctx.align_pairs_noalloc(n, *[x.ptr for x in d])             # ... and a large one (one lane per pair)
+            before = free_bytes()
+            ctx.align_pairs_noalloc(n, *[x.ptr for x in d])
+            ctx.align_pairs_noalloc(1000, *[x.ptr for x in d])
+            assert free_bytes() == before
+        finally:
+            for x in d:
+                x.free()
+    finally:
+        ctx.close()
+
+
+def test_overlapping_calls_on_one_gpu_are_refused_not_raced():
+    """two host threads with a context each on the same GPU: every call either gives the right answer or is refused
+    with PG_ERR_STATE (the GPU's fixed array was in use); nothing else, and never a wrong number"""
+    import threading
+    from platypus_amd import native, synth
+    from tests.hipmem import DeviceArray
+    b = synth.make_batch(n_windows=400, haps_per_window=5, reads_per_window=40, read_len=120, hap_len=500,
+                         indel_hap_frac=0.6, ragged=True, seed=78)
+    n = len(b["pair_hap"])
+    ref_ctx = native.AlignContext(0)
+    try:
+        ref_ctx.upload_batch(b)
+        ref_ctx.launch()
+        want = ref_ctx.fetch()
+    finally:
+        ref_ctx.close()
+    outcomes = [[], []]
+    errors = []
+
+    def worker(slot):
+        try:
+            ctx = native.AlignContext(0)
+            try:
+                ctx.upload_haps(b["hap_seq"], b["hap_off"], b["hap_start"], b["hap_varlen"])
+                ctx.upload_reads(b["read_seq"], b["read_qual"], b["read_off"], b["read_pos"], b["read_mapq"])
+                d = [DeviceArray(n, np.int32, b["pair_hap"]), DeviceArray(n, np.int32, b["pair_read"]),
+                     DeviceArray(n, np.int32), DeviceArray(n, np.int32), DeviceArray(n, np.float64)]
+                try:
+                    for _ in range(40):
+                        try:
+                            ctx.align_pairs_noalloc(n, *[x.ptr for x in d])
+                        except native.PlatGpuError as e:
+                            assert e.code == native.PG_ERR_STATE, str(e)
+                            outcomes[slot].append("refused")
+                            continue
+                        got = (d[2].numpy(), d[3].numpy(), d[4].numpy())
+                        _same(got, want)
+                        outcomes[slot].append("right")
+                finally:
+                    for x in d:
+                        x.free()
+            finally:
+                ctx.close()
+        except BaseException as e:      # noqa: B036  (reported by the main thread)
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert all(len(o) == 40 for o in outcomes)
+    assert any(x == "right" for o in outcomes for x in o)
