@@ -46,7 +46,7 @@ NOMINAL_LANE_RATE = 256 * 4 * 32 * 2.4e9   # CUs x SIMDs x lanes per clock x 2.4
 LDS_LOOKUP_PEAK = 75e12 / 4                # 4-byte LDS reads per second, all CUs streaming
 # VALU instructions one wavefront of k_align2 executes for reads of L bases: VALU_A + VALU_B * (L + 8)
 VALU_A, VALU_B = 653.8, 164.367
-VALU_SOURCE = ("profiles/r02_valu_insts.csv: SQ_INSTS_VALU / SQ_WAVES of k_align2 at L = 100, 150, 250 "
+VALU_SOURCE = ("profiles/r03_valu_insts.csv (the same counts as r02: the kernel did not change): SQ_INSTS_VALU / SQ_WAVES of k_align2 at L = 100, 150, 250 "
                "(18405.4, 26625.4, 43060.4 per wavefront; the line fits them within 2; tools/valu_count.sh)")
 
 
