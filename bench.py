@@ -43,7 +43,10 @@ import numpy as np  # noqa: E402
 
 OPS_PER_CELL = 14          # int16 ALU operations per DP cell of the reference recurrence
 NOMINAL_LANE_RATE = 256 * 4 * 32 * 2.4e9   # CUs x SIMDs x lanes per clock x 2.4 GHz: VALU lane-instructions per second
-LDS_LOOKUP_PEAK = 75e12 / 4                # 4-byte LDS reads per second, all CUs streaming
+# VALU instructions one wavefront of 64 pairs of k_vote5 executes (SQ_INSTS_VALU over the wavefronts that hold pairs)
+VOTE_VALU_PER_WAVE = 1740.0
+VOTE_VALU_SOURCE = ("profiles/r03_pmc_summary.csv (wgs stream: 21.79 M per launch of 782 336 pairs = 1782 per wavefront) and "
+                    "profiles/r03_pmc_vote_panel.csv (92.46 M per 3 495 040 pairs = 1693)")
 # VALU instructions one wavefront of k_align2 executes for reads of L bases: VALU_A + VALU_B * (L + 8)
 VALU_A, VALU_B = 653.8, 164.367
 VALU_SOURCE = ("profiles/r03_valu_insts.csv (the same counts as r02: the kernel did not change): SQ_INSTS_VALU / SQ_WAVES of k_align2 at L = 100, 150, 250 "
@@ -228,15 +231,16 @@ def roofline_of(n_pairs, L, k_ms, v_ms, n_vote_pairs, workload, probe=None, pk_p
         # that, so this is not a fraction of anything the hardware limits)
         roofline.update({"algorithmic_ops_per_s": algo_ops / k_avg / 1e12, "packed_int16_probe": pk_peak / 1e12,
                          "algorithmic_frac": algo_ops / k_avg / pk_peak})
-    # the anchoring kernel in front of it is bound by LDS look-up latency / issue: one table
-    # look-up per 7-mer of every read of a pair on an indel-bearing haplotype
+    # the anchoring kernel in front of it (k_vote5: exact bit-parallel vote counts, one lane per pair) executes about
+    # VOTE_VALU_PER_WAVE VALU instructions per wavefront of 64 pairs; its share of the issue rate is low because one
+    # launch of many short workgroups spends as long setting up (rows of four haplotypes into LDS, a barrier) as counting
     v_avg = float(np.mean(v_ms)) * 1e-3
-    lookups = float(n_vote_pairs) * max(0, L - 7)
+    vote_rate = float((n_vote_pairs + 63) // 64) * VOTE_VALU_PER_WAVE * 64.0 / v_avg if v_avg > 0 else None
     roofline_anchor = {
-        "bound": "lds_lookup", "kernel": "k_vote", "kernel_ms": v_avg * 1e3, "pairs": n_vote_pairs,
-        "achieved": lookups / v_avg / 1e12 if v_avg > 0 else None, "peak": LDS_LOOKUP_PEAK / 1e12,
-        "unit": "T look-ups/s", "frac": lookups / v_avg / LDS_LOOKUP_PEAK if v_avg > 0 else None,
-        "peak_source": "ds_read_b32 aggregate of the chip, 75 TB/s / 4 B",
+        "bound": "valu_issue", "kernel": "k_vote5", "kernel_ms": v_avg * 1e3, "pairs": n_vote_pairs,
+        "achieved": vote_rate / 1e12 if vote_rate else None, "peak": NOMINAL_LANE_RATE / 1e12,
+        "unit": "T lane-instructions/s", "frac": vote_rate / NOMINAL_LANE_RATE if vote_rate else None,
+        "valu_insts_per_wave": VOTE_VALU_PER_WAVE, "valu_insts_source": VOTE_VALU_SOURCE,
     }
     return roofline, roofline_anchor
 
