@@ -9,7 +9,10 @@ single or ragged), haplotype length (60..2000), share of indel haplotypes, homop
 share, substitution and read-indel rates; then reads are moved (some far enough to hang off the
 haplotype or to trip the assertion of calign.pyx:61), qualities get extremes (0, 93, 127), read
 bases get 'N's, mapping qualities cover 0..255, the pair list is a shuffled subset with repeats,
-and one batch in four uses other gap parameters.  Scores and anchors must be equal, likelihoods
+and one batch in four uses other gap parameters.  The alignment kernel (one lane per pair, eight
+lanes per pair) is the library's choice for the batch's size in half of the batches and forced to one
+or the other in the rest; one batch in three also goes window by window through pg_align_window
+(dense windows, before the pair list is shuffled).  Scores and anchors must be equal, likelihoods
 the same doubles.  Prints one line per mismatching batch and a summary; exit status 1 on any."""
 import math
 import os
@@ -48,6 +51,8 @@ def make(seed):
     s[rng.random(len(s)) < float(rng.choice([0.0, 0.002, 0.05]))] = ord("N")
     b["read_mapq"] = np.where(rng.random(nR) < 0.1, rng.integers(0, 256, nR), b["read_mapq"]).astype(np.int32)
     n = len(b["pair_hap"])
+    b["dense"] = (b["pair_hap"].copy(), b["pair_read"].copy()) if rng.random() < 1.0 / 3 else None
+    b["align_kernel"] = str(rng.choice(["default", "default", "lane", "band"]))
     pick = rng.integers(0, n, size=int(rng.integers(1, 2 * n + 1)))
     b["pair_hap"], b["pair_read"] = b["pair_hap"][pick].copy(), b["pair_read"][pick].copy()
     params = (3, 2, po.HOMOPOLQ)
@@ -63,7 +68,7 @@ def main():
     use_ref = po.have_ref()
     ctx = native.AlignContext(0)
     t0 = time.perf_counter()
-    n_batches = n_pairs = n_bad = n_assert = n_refused = 0
+    n_batches = n_pairs = n_bad = n_assert = n_refused = n_window_pairs = 0
     mLTOT = -0.23025850929940459
     last_report = t0
     while time.perf_counter() - t0 < budget:
@@ -73,6 +78,15 @@ def main():
         b, (ge, npr, tab) = make(seed)
         try:
             ctx.set_params(ge, npr, tab)
+            ctx.set_option("align_kernel", b["align_kernel"])
+            windows = None
+            if b["dense"] is not None:                           # window by window, every haplotype x every read
+                m = b["meta"]
+                H, R = m["haps_per_window"], m["reads_per_window"]
+                windows = [ctx.align_window(b["hap_seq"], b["hap_off"][w * H:(w + 1) * H + 1], b["hap_start"][w * H:(w + 1) * H],
+                                            b["hap_varlen"][w * H:(w + 1) * H], b["read_seq"], b["read_qual"],
+                                            b["read_off"][w * R:(w + 1) * R + 1], b["read_pos"][w * R:(w + 1) * R],
+                                            b["read_mapq"][w * R:(w + 1) * R]) for w in range(m["windows"])]
             ctx.upload_batch(b)
             ctx.launch()
             score, anchor, like = ctx.fetch()
@@ -89,6 +103,20 @@ def main():
                          min(1.0, math.exp(mLTOT * s) * (1.0 - math.exp(mLTOT * m)) + math.exp(mLTOT * m))
                          for s, m in zip(cs.tolist(), mq.tolist())])
         ok = ok and np.array_equal(want, like)
+        if windows is not None:
+            d = dict(synth.oracle_view(b))
+            d["pair_hap"], d["pair_read"] = b["dense"]
+            ds, da = po.run_pairs(d, use_ref=use_ref, gapextend=ge, nucprior=npr, table=tab)
+            dq = b["read_mapq"][d["pair_read"]]
+            dl = np.array([0.0 if s == native.PG_SCORE_ASSERT_FAILED else
+                           min(1.0, math.exp(mLTOT * s) * (1.0 - math.exp(mLTOT * m)) + math.exp(mLTOT * m))
+                           for s, m in zip(ds.tolist(), dq.tolist())])
+            ws = np.concatenate([w[0] for w in windows]); wa = np.concatenate([w[1] for w in windows])
+            wl = np.concatenate([w[2] for w in windows])
+            if not (np.array_equal(ws, ds) and np.array_equal(wa, da) and np.array_equal(wl, dl)):
+                ok = False
+                print("seed %d: the window calls differ from the checker" % seed, flush=True)
+            n_window_pairs += len(ds)
         n_assert += int((cs == native.PG_SCORE_ASSERT_FAILED).sum())
         if not ok:
             n_bad += 1
@@ -100,8 +128,8 @@ def main():
         n_pairs += len(cs)
         seed += 1
     ctx.close()
-    print("%d batches, %d pairs (%d with the swallowed assertion), %d batches refused as outside the domain, "
-          "%d batches with differences; DP checker: %s" % (n_batches, n_pairs, n_assert, n_refused, n_bad,
+    print("%d batches, %d pairs (%d with the swallowed assertion) and %d more through window calls, %d batches refused as "
+          "outside the domain, %d batches with differences; DP checker: %s" % (n_batches, n_pairs, n_assert, n_window_pairs, n_refused, n_bad,
                                                             "reference align.c" if use_ref else "restatement"))
     return 1 if n_bad else 0
 
