@@ -302,6 +302,26 @@ def cpu_baseline(batch, n_pairs, L, score, anchor):
 
 
 # ------------------------------------------------------------------------------------------------------
+def join_group(rank, world):
+    """The control plane of a run started by torch.distributed.run: a gloo group on the host (a barrier and one MAX);
+    nothing of torch touches the GPU.  gloo announces its connections on the C++ standard output; this program's
+    standard output carries one JSON line and nothing else, so descriptor 1 points at standard error while the group
+    is being set up."""
+    import datetime
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=30))
+        dist.barrier()
+    finally:
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
+    return dist
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -333,11 +353,7 @@ def main():
 
     dist = None
     if launched:
-        # control plane only (a barrier and one MAX); gloo on the host, nothing of torch touches the GPU
-        import datetime
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=30))
+        dist = join_group(rank, world)
 
     # ---- file to file (simulated BAM + FASTA -> VCF through the region caller), not part of the metric:
     # the second figure BASELINE.json names, Mbp/min.  It runs first, while no process of this run has
@@ -462,8 +478,19 @@ def _dry_child(rank, world, barrier, conn):
 def dry_run(args, world, launched, rank):
     """The launcher without a GPU: starts the ranks the way the real run does, lines them up on the same barriers
     and prints one line with n_gpus = the ranks that ran (what the CPU tests call)."""
-    if launched:
-        raise SystemExit("--dry-run is for the self-launched mode")
+    if launched:                                 # under torch.distributed.run: the group, a barrier, one line from rank 0
+        dist = join_group(rank, world)
+        t0 = time.perf_counter()
+        dist.barrier()
+        gathered = [None] * world
+        dist.all_gather_object(gathered, dict(rank=rank, dt=time.perf_counter() - t0, pid=os.getpid()))
+        dist.barrier()
+        dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"metric": "read_x_haplotype_align_gcups", "dry_run": True, "n_gpus": world,
+                              "seconds": max(g["dt"] for g in gathered),
+                              "ranks": [dict(rank=g["rank"], seconds=g["dt"], pid=g["pid"]) for g in gathered]}), flush=True)
+        return
     import multiprocessing
     mp = multiprocessing.get_context("spawn")
     barrier = mp.Barrier(world)

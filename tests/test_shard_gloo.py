@@ -110,3 +110,22 @@ def test_bench_launches_its_own_ranks():
     assert len(pids) == 2 and res["parent_pid"] not in pids            # ranks are processes of their own
     assert res["seconds"] == max(r["seconds"] for r in res["ranks"]) and 0.09 < res["seconds"] < 5.0
     assert res["ranks"][1]["seconds"] > res["ranks"][0]["seconds"] - 0.02  # both left the first barrier together
+
+
+def test_bench_under_a_launcher_prints_one_line_and_nothing_else():
+    """started by torch.distributed.run the ranks join a gloo group; gloo announces its connections on the C++ standard
+    output, which must not reach this program's: one JSON line from rank 0, byte for byte"""
+    import json
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    done = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                           "--gpus", "2", "--dry-run"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert done.returncode == 0, done.stderr[-2000:]
+    assert done.stdout.count("\n") == 1 and done.stdout.startswith("{"), done.stdout[:400]
+    res = json.loads(done.stdout)
+    assert res["n_gpus"] == 2 and [r["rank"] for r in res["ranks"]] == [0, 1]
+    assert len({r["pid"] for r in res["ranks"]}) == 2
