@@ -3,8 +3,9 @@
 sequence, support counters, prior.  Candidate generation from CIGAR strings
 (variant.pyx:253-615) is upstream of the alignment path and not part of this package."""
 from libc.math cimport exp, sqrt
-from libc.stdint cimport int32_t, int64_t
+from libc.stdint cimport int32_t, int64_t, uint64_t
 from libc.stdlib cimport calloc, malloc, realloc, free
+from libc.string cimport memcpy
 
 cdef double mLTOT = -0.23025850929940459    # minus log ten over ten
 
@@ -185,11 +186,27 @@ cdef class VariantCandidateGenerator:
         cdef SnpSums* grown
         cdef int nRef = self.nRef
         cdef char readChar, refChar
-        for index in range(lenSeqToCheck):
+        # positions with a reference base and a read base to compare: index in [lo, hi)
+        cdef int lo = 0, hi = lenSeqToCheck, shift = refOffset + readStart - self.refSeqStart
+        cdef uint64_t a, b
+        if shift < 0:
+            lo = -shift
+        if hi > nRef - shift:
+            hi = nRef - shift
+        if hi > read.rlen - readOffset:
+            hi = read.rlen - readOffset
+        index = lo
+        while index < hi:
+            # eight equal bases at once: almost every stretch of a read equals the reference
+            if index + 8 <= hi:
+                memcpy(&a, read.seq + readOffset + index, 8)
+                memcpy(&b, self.refSeq + shift + index, 8)
+                if a == b:
+                    index += 8
+                    continue
             readIndex = index + readOffset
-            refIndex = (index + refOffset + readStart) - self.refSeqStart
-            if refIndex < 0 or refIndex >= nRef or readIndex >= read.rlen:
-                continue                                   # beyond the cached reference: nothing to compare with
+            refIndex = index + shift
+            index += 1
             readChar = read.seq[readIndex]
             refChar = self.refSeq[refIndex]
             baseQual = read.qual[readIndex]
