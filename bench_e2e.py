@@ -144,6 +144,19 @@ def _timing_report(stderr_texts):
             seen = True
         for m in re.finditer(r"from (\d+) candidates in (\d+) windows \((\d+) with reads", text):
             counts["candidates"] += int(m.group(1)); counts["windows"] += int(m.group(2)); counts["windows_called"] += int(m.group(3))
+    k = {"pairs": 0, "cells": 0, "anchor_ms": 0.0, "align_ms": 0.0, "setup_ms": 0.0, "em_ms": 0.0}
+    for text in stderr_texts:
+        for m in re.finditer(r"device batches: (\d+) pairs, (\d+) cells, anchoring ([\d.]+) ms, alignment ([\d.]+) ms, "
+                             r"genotype set-up ([\d.]+) ms, EM ([\d.]+) ms", text):
+            k["pairs"] += int(m.group(1)); k["cells"] += int(m.group(2))
+            for name, g in zip(("anchor_ms", "align_ms", "setup_ms", "em_ms"), m.groups()[2:]):
+                k[name] += float(g)
+    if k["pairs"]:
+        # the DP kernel on the run's own pair stream (cells as the reference's loop executes them, 16 (L + 8) per pair)
+        k["align_gcups"] = k["cells"] / (k["align_ms"] * 1e-3) / 1e9 if k["align_ms"] > 0 else None
+        k["what"] = ("every device batch of the one-process run: pairs aligned, DP cells, kernel times from HIP events; one batch per "
+                     "1-Mb stretch, so the launches are a few thousand to a few hundred thousand pairs each")
+        counts["pair_stream"] = k
     return (dev if seen else None), counts
 
 
