@@ -144,12 +144,13 @@ def _timing_report(stderr_texts):
             seen = True
         for m in re.finditer(r"from (\d+) candidates in (\d+) windows \((\d+) with reads", text):
             counts["candidates"] += int(m.group(1)); counts["windows"] += int(m.group(2)); counts["windows_called"] += int(m.group(3))
-    k = {"pairs": 0, "cells": 0, "anchor_ms": 0.0, "align_ms": 0.0, "setup_ms": 0.0, "em_ms": 0.0}
+    k = {"pairs": 0, "cells": 0, "vote_pairs": 0, "vote_named": 0, "vote_full": 0, "anchor_ms": 0.0, "align_ms": 0.0, "setup_ms": 0.0, "em_ms": 0.0}
     for text in stderr_texts:
-        for m in re.finditer(r"device batches: (\d+) pairs, (\d+) cells, anchoring ([\d.]+) ms, alignment ([\d.]+) ms, "
+        for m in re.finditer(r"device batches: (\d+) pairs, (\d+) cells, (\d+) pairs anchored by votes \((\d+) \+ (\d+) of them counted by a wavefront\), anchoring ([\d.]+) ms, alignment ([\d.]+) ms, "
                              r"genotype set-up ([\d.]+) ms, EM ([\d.]+) ms", text):
             k["pairs"] += int(m.group(1)); k["cells"] += int(m.group(2))
-            for name, g in zip(("anchor_ms", "align_ms", "setup_ms", "em_ms"), m.groups()[2:]):
+            k["vote_pairs"] += int(m.group(3)); k["vote_named"] += int(m.group(4)); k["vote_full"] += int(m.group(5))
+            for name, g in zip(("anchor_ms", "align_ms", "setup_ms", "em_ms"), m.groups()[5:]):
                 k[name] += float(g)
     if k["pairs"]:
         # the DP kernel on the run's own pair stream (cells as the reference's loop executes them, 16 (L + 8) per pair)

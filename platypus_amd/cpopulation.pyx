@@ -434,6 +434,7 @@ cdef class WindowBatch:
         cdef int32_t* p_read = <int32_t*>malloc((nPairs + 1) * sizeof(int32_t))
         cdef int hl
         cdef float kms[5]
+        cdef int64_t votes[3]
         cdef list out = []
         global g_generation
         try:
@@ -503,6 +504,8 @@ cdef class WindowBatch:
             for w in range(5):                                    # anchor, alignment, genotype, setup, EM (platgpu.h)
                 kms[w] = 0.0
                 pg_kernel_time_ms(ctx, w, &kms[w])
+            votes[0] = votes[1] = votes[2] = 0
+            pg_anchor_stats(ctx, votes)                           # pairs anchored by votes; of those, counted by a wavefront
             self.pairBase = [base[w] for w in range(nW)]          # pair index of (haplotype 0, read 0) of every window
             hi = 0; ii = 0; ci = 0
             for w in range(nW):
@@ -516,7 +519,7 @@ cdef class WindowBatch:
             t4 = time.perf_counter()
             self.timings = dict(pack=t1 - t0, upload=t2 - t1, device=t3 - t2, unpack=t4 - t3,
                                 windows=nW, haplotypes=int(nHapTot), reads=int(nReadTot), read_incidences=int(nInc), pairs=int(nPairs),
-                                cells=int(nCellsDP), anchor_ms=kms[0], align_ms=kms[1], setup_ms=kms[3], em_ms=kms[4])
+                                cells=int(nCellsDP), vote_pairs=int(votes[0]), vote_named=int(votes[1]), vote_full=int(votes[2]), anchor_ms=kms[0], align_ms=kms[1], setup_ms=kms[3], em_ms=kms[4])
         finally:
             free(hoff); free(hstart); free(hvl); free(hbuf); free(roff); free(rpos); free(rmq); free(sbuf); free(qbuf)
             free(b_hlo); free(b_nh); free(b_rlo); free(b_nr); free(w_ni); free(base); free(ioff); free(nreads)

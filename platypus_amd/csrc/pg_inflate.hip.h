@@ -446,6 +446,64 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate_wave(const unsigned char* _
         return P;
     };
 
+    // One token decoded the ordinary way at a bit position (every lane the same; the results are scalars): what the
+    // direct tables do not hold, and what the chain could not take.
+    struct Tok { int kind; uint32_t size, dist, lit; int bits; int err; };   // kind 1 literal, 2 match, 3 end of block
+    auto slow_token = [&](uint32_t bp, int n_lit, int n_dst) -> Tok {
+        Tok t{0, 0u, 0u, 0u, 0, INF_OK};
+        InflPeek P = peek64(bp);
+        const uint32_t ej = T.u16(IT_FAST, (int)((uint32_t)P.bb & ((1u << IT_FAST_BITS) - 1)));
+        int s;
+        if (ej != 0) {
+            s = (int)(ej & 511u);
+            P.bb >>= ej >> 9;
+            P.bc -= (int)(ej >> 9);
+        } else {
+            s = infl_decode(T, P, IT_LIT_SYM, IT_LIT_THR, IT_LIT_BASE, n_lit);
+        }
+        s = __builtin_amdgcn_readfirstlane(s);
+        if (s < 0) { t.err = INF_BAD_CODE; return t; }
+        if (s < 256) { t.kind = 1; t.size = 1; t.lit = (uint32_t)s; }
+        else if (s == 256) { t.kind = 3; }
+        else {
+            s -= 257;
+            if (s >= 29) { t.err = INF_BAD_CODE; return t; }
+            uint32_t len;
+            if (s < 8) len = 3u + (uint32_t)s;
+            else if (s == 28) len = 258u;
+            else {
+                const int x = (s - 4) >> 2;
+                len = 3u + ((4u + ((uint32_t)s & 3u)) << x) + ((uint32_t)P.bb & ((1u << x) - 1u));
+                P.bb >>= x;
+                P.bc -= x;
+            }
+            int d;
+            const uint32_t dq = T.u16(IT_DFAST, (int)((uint32_t)P.bb & ((1u << IT_DFAST_BITS) - 1)));
+            if (dq) {
+                d = (int)(dq & 511u);
+                P.bb >>= dq >> 9;
+                P.bc -= (int)(dq >> 9);
+            } else {
+                d = infl_decode(T, P, IT_DST_SYM, IT_DST_THR, IT_DST_BASE, n_dst);
+            }
+            d = __builtin_amdgcn_readfirstlane(d);
+            if (d < 0 || d >= 30) { t.err = INF_BAD_CODE; return t; }
+            uint32_t dist;
+            if (d < 4) dist = 1u + (uint32_t)d;
+            else {
+                const int x = (d >> 1) - 1;
+                dist = 1u + ((2u + ((uint32_t)d & 1u)) << x) + ((uint32_t)P.bb & ((1u << x) - 1u));
+                P.bb >>= x;
+                P.bc -= x;
+            }
+            t.kind = 2;
+            t.size = (uint32_t)__builtin_amdgcn_readfirstlane((int)len);
+            t.dist = (uint32_t)__builtin_amdgcn_readfirstlane((int)dist);
+        }
+        t.bits = __builtin_amdgcn_readfirstlane(64 - P.bc);
+        return t;
+    };
+
     uint32_t bitpos = 8u * lead;                                              // everything below is the same in every lane
     uint32_t op = 0;                                                          // bytes of output so far
     int n_lit = 0, n_dst = 0;
@@ -572,7 +630,9 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate_wave(const unsigned char* _
         uint32_t kind = 0, tlen = 0, size = 0, dist = 0, lit = 0;             // kind: 0 stop here, 1 literal, 2 match
         {
             const uint32_t p = bitpos + (uint32_t)lane, w = p >> 5, sh = p & 31u;
-            const uint32_t a = iring[w & (IW_IN_WORDS - 1)], c = iring[(w + 1) & (IW_IN_WORDS - 1)], d = iring[(w + 2) & (IW_IN_WORDS - 1)];
+            const uint32_t a = iring[w & (IW_IN_WORDS - 1)], c = iring[(w + 1) & (IW_IN_WORDS - 1)];
+            uint32_t d = iring[(w + 2) & (IW_IN_WORDS - 1)];
+            asm volatile("" : "+v"(d));                                       // all three words are asked for at once (one wait, not two)
             uint64_t v = ((uint64_t)__builtin_amdgcn_alignbit(d, c, sh) << 32) | __builtin_amdgcn_alignbit(c, a, sh);
             const uint32_t e = T.u16(IT_FAST, (int)((uint32_t)v & ((1u << IT_FAST_BITS) - 1)));
             const uint32_t sym = e & 511u;
@@ -606,17 +666,34 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate_wave(const unsigned char* _
         unsigned long long starts = 0;
         int j = 0;
         uint32_t P = 0, mypos = 0;                                            // bytes this pass writes; where this lane's token goes
+        // (scalar copies: the walk below then runs on the scalar unit, its lane reads apart)
+        const uint32_t op_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)op);
+        const uint32_t room_s = K.out_len - op_s;
+        const uint32_t bit_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)bitpos);
+        uint32_t n_max = 0;                                                   // the longest match of the pass
         while (j < 64) {
-            const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)kind, j);
-            if (kj == 0) break;
+            uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)kind, j);
+            if (kj == 0) {
+                // a code beyond the direct tables (a tenth of the tokens' chains would end here): decoded the ordinary way,
+                // handed to lane j, and the chain goes on; the end-of-block code and a bad code are left to the pass below
+                const Tok t = slow_token(bit_s + (uint32_t)j, n_lit, n_dst);
+                if (t.err || t.kind == 3) break;
+                kj = (uint32_t)t.kind;
+                kind = lane == j ? kj : kind;
+                size = lane == j ? t.size : size;
+                dist = lane == j ? t.dist : dist;
+                lit = lane == j ? t.lit : lit;
+                tlen = lane == j ? (uint32_t)t.bits : tlen;
+            }
             const uint32_t sz = (uint32_t)__builtin_amdgcn_readlane((int)size, j);
-            if (sz > K.out_len - op - P) break;
+            if (sz > room_s - P) break;
             if (kj == 2) {
                 const uint32_t dj = (uint32_t)__builtin_amdgcn_readlane((int)dist, j);
-                if (dj > op + P || dj < sz + P || sz > 32u || dj > (uint32_t)IW_OUT - 2304u) break;
+                if (dj > op_s + P || dj < sz + P || sz > 32u || dj > (uint32_t)IW_OUT - 2304u) break;
             }
-            mypos = lane == j ? op + P : mypos;
+            mypos = lane == j ? op_s + P : mypos;
             starts |= 1ull << j;
+            if (kj == 2) n_max = max(n_max, sz);
             P += sz;
             j += (int)__builtin_amdgcn_readlane((int)tlen, j);
         }
@@ -629,9 +706,6 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate_wave(const unsigned char* _
             // matches: every lane its own, four bytes read, then written (sources lie before the pass: no order among them;
             // at most 2 KiB are written in a pass, and no source is nearer than that to the ring's far end)
             const uint32_t n_mine = mine && kind == 2 ? size : 0u;
-            uint32_t n_max = n_mine;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) n_max = max(n_max, (uint32_t)__shfl_xor((int)n_max, o));
             for (uint32_t k0 = 0; k0 < n_max; k0 += 4) {
                 unsigned char x[4];
 #pragma unroll
@@ -645,56 +719,19 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate_wave(const unsigned char* _
         }
         bitpos += (uint32_t)j;
         if (!starts) {
-            // ---- a token the chain could not take, decoded the ordinary way (every lane the same) ----
-            InflPeek P = peek64(bitpos);
-            const uint32_t ej = T.u16(IT_FAST, (int)((uint32_t)P.bb & ((1u << IT_FAST_BITS) - 1)));
-            int s;
-            if (ej != 0) {
-                s = (int)(ej & 511u);
-                P.bb >>= ej >> 9;
-                P.bc -= (int)(ej >> 9);
-            } else {
-                s = infl_decode(T, P, IT_LIT_SYM, IT_LIT_THR, IT_LIT_BASE, n_lit);
-                if (s < 0) { err = INF_BAD_CODE; break; }
-            }
-            if (s < 256) {
+            // ---- a token the chain could not take (every lane the same) ----
+            const Tok t = slow_token(bitpos, n_lit, n_dst);
+            if (t.err) { err = t.err; break; }
+            if (t.kind == 1) {
                 if (op >= K.out_len) { err = INF_OUTPUT_OVERRUN; break; }
-                if (lane == 0) { oring[op & (IW_OUT - 1)] = (unsigned char)s; gout[op] = (unsigned char)s; }
+                if (lane == 0) { oring[op & (IW_OUT - 1)] = (unsigned char)t.lit; gout[op] = (unsigned char)t.lit; }
                 op += 1;
                 __builtin_amdgcn_wave_barrier();
-            } else if (s == 256) {
+            } else if (t.kind == 3) {
                 in_block = false;
                 if (last) done = true;
             } else {
-                s -= 257;
-                if (s >= 29) { err = INF_BAD_CODE; break; }
-                uint32_t len;
-                if (s < 8) len = 3u + (uint32_t)s;
-                else if (s == 28) len = 258u;
-                else {
-                    const int x = (s - 4) >> 2;
-                    len = 3u + ((4u + ((uint32_t)s & 3u)) << x) + ((uint32_t)P.bb & ((1u << x) - 1u));
-                    P.bb >>= x;
-                    P.bc -= x;
-                }
-                int d;
-                const uint32_t dq = T.u16(IT_DFAST, (int)((uint32_t)P.bb & ((1u << IT_DFAST_BITS) - 1)));
-                if (dq) {
-                    d = (int)(dq & 511u);
-                    P.bb >>= dq >> 9;
-                    P.bc -= (int)(dq >> 9);
-                } else {
-                    d = infl_decode(T, P, IT_DST_SYM, IT_DST_THR, IT_DST_BASE, n_dst);
-                }
-                if (d < 0 || d >= 30) { err = INF_BAD_CODE; break; }
-                uint32_t dist;
-                if (d < 4) dist = 1u + (uint32_t)d;
-                else {
-                    const int x = (d >> 1) - 1;
-                    dist = 1u + ((2u + ((uint32_t)d & 1u)) << x) + ((uint32_t)P.bb & ((1u << x) - 1u));
-                    P.bb >>= x;
-                    P.bc -= x;
-                }
+                const uint32_t len = t.size, dist = t.dist;
                 if (dist > op) { err = INF_BAD_DISTANCE; break; }
                 if (len > K.out_len - op) { err = INF_OUTPUT_OVERRUN; break; }
                 if (dist >= 64) {
@@ -719,7 +756,7 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate_wave(const unsigned char* _
                 op += len;
                 __builtin_amdgcn_wave_barrier();
             }
-            bitpos += (uint32_t)(64 - P.bc);
+            bitpos += (uint32_t)t.bits;
         }
         feed(bitpos >> 5);
     }

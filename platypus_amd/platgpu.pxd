@@ -45,3 +45,4 @@ cdef extern from "platgpu.h":
     int pg_hash_sequence(pg_ctx* ctx, const char* seq, int len, int32_t* table)
     int pg_map_read(pg_ctx* ctx, const char* read, int read_len, int seq_len, const int32_t* table, int32_t* position)
     int pg_kernel_time_ms(pg_ctx* ctx, int which, float* ms)
+    int pg_anchor_stats(pg_ctx* ctx, int64_t* counts)

@@ -68,7 +68,7 @@ def call_chunks(chunks, args, tmpdir):
     spent = {"fetch": 0.0, "buffers": 0.0, "candidates": 0.0, "wait": 0.0, "call": 0.0, "write": 0.0}
     counts = {"windows": 0, "called_windows": 0, "candidates": 0}
     phases = {}                                           # seconds per phase of callRegion, summed (timing report only)
-    kernels = {"pairs": 0, "cells": 0, "anchor_ms": 0.0, "align_ms": 0.0, "setup_ms": 0.0, "em_ms": 0.0}   # the device batches' own counts
+    kernels = {"pairs": 0, "cells": 0, "vote_pairs": 0, "vote_named": 0, "vote_full": 0, "anchor_ms": 0.0, "align_ms": 0.0, "setup_ms": 0.0, "em_ms": 0.0}   # the device batches' own counts
     timed = bool(os.environ.get("PLATYPUS_AMD_TIMINGS"))
 
     local = threading.local()
@@ -216,8 +216,8 @@ def call_chunks(chunks, args, tmpdir):
                              os.getpid(), n_calls, counts["candidates"], counts["windows"], counts["called_windows"], spent["fetch"], spent["buffers"], spent["candidates"], spent["wait"],
                              spent["call"], spent["write"],
                              ", ".join("%s %.2f" % (k, v) for k, v in sorted(phases.items()))))
-        sys.stderr.write("worker %d: device batches: %d pairs, %d cells, anchoring %.3f ms, alignment %.3f ms, genotype set-up %.3f ms, EM %.3f ms\n" % (
-            os.getpid(), kernels["pairs"], kernels["cells"], kernels["anchor_ms"], kernels["align_ms"], kernels["setup_ms"], kernels["em_ms"]))
+        sys.stderr.write("worker %d: device batches: %d pairs, %d cells, %d pairs anchored by votes (%d + %d of them counted by a wavefront), anchoring %.3f ms, alignment %.3f ms, genotype set-up %.3f ms, EM %.3f ms\n" % (
+            os.getpid(), kernels["pairs"], kernels["cells"], kernels["vote_pairs"], kernels["vote_named"], kernels["vote_full"], kernels["anchor_ms"], kernels["align_ms"], kernels["setup_ms"], kernels["em_ms"]))
     return n_calls
 
 
