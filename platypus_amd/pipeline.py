@@ -70,25 +70,47 @@ def convertVariantToStandardFormat(variant, refFile, maxReadLength):
     windowMin = max(1, variant.refPos - window)
     windowMax = min(variant.refPos + window, seqMax)
     ref = refFile.getSequence(variant.refName, windowMin, windowMax)
-    hap = chaplotype.Haplotype(variant.refName, windowMin, windowMax, (variant,), refFile, 0).sequence
-    lenRef, lenHap = len(ref), len(hap)
-    # the first mismatch from the right = the length of the longest common suffix; 'a suffix of
-    # length k matches' is monotone in k, so it is found by bisection over slice comparisons
-    lo, hi = 0, min(lenRef, lenHap)
-    while lo < hi:
-        mid = (lo + hi + 1) >> 1
-        if hap[lenHap - mid:] == ref[lenRef - mid:]:
-            lo = mid
-        else:
-            hi = mid - 1
-    index = lo
+    lenRef = len(ref)
+    lenHap = lenRef + nAdded - nRemoved
+    # The reference builds the mutated sequence over the window (ref[:a] + added + ref[a + nRemoved:], a = the bases up
+    # to and including refPos, chaplotype.pyx:283-353) and looks for the first mismatch from the right.  Right of the
+    # variant the two are the same bases (`tail` of them); from there on the comparison is made here base by base
+    # without building the sequence -- an indel moves by the length of the repeat it sits in, a few bases.
+    a = variant.refPos + 1 - windowMin
+    tail = lenRef - (a + nRemoved)
+    if a < 1 or tail < 0:                                            # (a variant hanging over the window's end: the literal way)
+        hap = chaplotype.Haplotype(variant.refName, windowMin, windowMax, (variant,), refFile, 0).sequence
+        lenHap = len(hap)
+        lo, hi = 0, min(lenRef, lenHap)
+        while lo < hi:
+            mid = (lo + hi + 1) >> 1
+            if hap[lenHap - mid:] == ref[lenRef - mid:]:
+                lo = mid
+            else:
+                hi = mid - 1
+        index = lo
+        hapAt = hap.__getitem__
+    else:
+        added = variant.added
+
+        def hapAt(x):                                                 # byte x of the mutated sequence
+            if x < a:
+                return ref[x]
+            if x < a + nAdded:
+                return added[x - a]
+            return ref[x - nAdded + nRemoved]
+
+        index = tail
+        limit = min(lenRef, lenHap)
+        while index < limit and hapAt(lenHap - 1 - index) == ref[lenRef - 1 - index]:
+            index += 1
     if index >= min(lenRef, lenHap):
         raise ValueError("Error in variant conversion to standard format. Variant = %s" % variant)
     newAdded, newRemoved, newPos = b"", b"", -1
     if nAdded > 0:
         newPos = windowMin + (lenRef - 1) - index
         insStart = newPos - windowMin + 1
-        newAdded = hap[insStart:insStart + nAdded]
+        newAdded = bytes(hapAt(x) for x in range(insStart, min(insStart + nAdded, lenHap)))
     if nRemoved > 0:
         newPos = windowMin + (lenRef - 1) - index - nRemoved
         delStart = newPos - windowMin + 1

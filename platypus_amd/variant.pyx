@@ -140,9 +140,15 @@ cdef class VariantCandidateGenerator:
     cdef int32_t* snpIndex
     cdef SnpSums* snpSums
     cdef int nSnpSums, capSnpSums
+    # insertions, deletions and letters other than A, C, G, T: the same sums per (position, removed, added), found through
+    # a dictionary that keeps the order of first sight (the order their Variant objects entered the heap in)
+    cdef dict objIndex
+    cdef dict deletedSeq                     # (position, length) -> the deleted bases, None if they hold an 'N'
+    cdef SnpSums* objSums
+    cdef int nObjSums, capObjSums
 
     def __dealloc__(self):
-        free(self.snpIndex); free(self.snpSums)
+        free(self.snpIndex); free(self.snpSums); free(self.objSums)
 
     def __cinit__(self):
         self.droppedSnpPositions = []
@@ -161,7 +167,12 @@ cdef class VariantCandidateGenerator:
         self.capSnpSums = 4096
         self.nSnpSums = 0
         self.snpSums = <SnpSums*>malloc(self.capSnpSums * sizeof(SnpSums))
-        if not (self.snpIndex and self.snpSums):
+        self.objIndex = {}
+        self.deletedSeq = {}
+        self.capObjSums = 1024
+        self.nObjSums = 0
+        self.objSums = <SnpSums*>malloc(self.capObjSums * sizeof(SnpSums))
+        if not (self.snpIndex and self.snpSums and self.objSums):
             raise MemoryError()
         self.minMapQual = minMapQual
         self.minBaseQual = minBaseQual
@@ -241,6 +252,40 @@ cdef class VariantCandidateGenerator:
                     acc.fwdW += 1.0 - exp(mLTOT * baseQual)
         return rc
 
+    cdef int countOccurrence(self, int refPos, bytes removed, bytes added, int isReverse, int baseQual, int readPos) except -1:
+        """one read's support for a candidate that is no single-base A/C/G/T mismatch: what Variant.__init__ and
+        addVariant (variant.pyx:57-76,107-119) add up, in read order, without an object per occurrence"""
+        cdef SnpSums* acc
+        cdef SnpSums* grown
+        cdef int k
+        if refPos < 0:
+            refPos = 0                                     # variant.pyx:38
+        key = (refPos, removed, added)
+        slot = self.objIndex.get(key)
+        if slot is None:
+            if self.nObjSums == self.capObjSums:
+                grown = <SnpSums*>realloc(self.objSums, 2 * <size_t>self.capObjSums * sizeof(SnpSums))
+                if grown == NULL:
+                    raise MemoryError()
+                self.objSums = grown
+                self.capObjSums *= 2
+            k = self.nObjSums
+            self.nObjSums += 1
+            self.objIndex[key] = k
+            acc = &self.objSums[k]
+            acc.slot = 0; acc.n = 0; acc.fwd = 0; acc.sumSq = 0; acc.fwdW = 0.0; acc.revW = 0.0
+        else:
+            k = slot
+            acc = &self.objSums[k]
+        acc.n += 1
+        acc.sumSq += <int64_t>readPos * readPos
+        if isReverse:
+            acc.revW += 1.0 - exp(mLTOT * baseQual)
+        else:
+            acc.fwd += 1
+            acc.fwdW += 1.0 - exp(mLTOT * baseQual)
+        return 0
+
     cdef otherLettersInSegment(self, cAlignedRead* read, int readStart, int readOffset, int refOffset, int lenSeqToCheck):
         """the same walk for read letters other than A, C, G, T, N: one Variant object each (rare)"""
         cdef int index, readIndex, refIndex, baseQual
@@ -255,9 +300,8 @@ cdef class VariantCandidateGenerator:
             baseQual = read.qual[readIndex]
             if (readChar != refChar and readChar != b'N' and refChar != b'N' and baseQual >= self.minBaseQual
                     and readChar != b'A' and readChar != b'C' and readChar != b'G' and readChar != b'T'):
-                self.addVariantToList(Variant(self.rname, refIndex + self.refSeqStart, bytes([refChar]),
-                                              bytes([readChar]), 1, 0 if read.isReverse else 1, read.mapq,
-                                              baseQual, readIndex + 1))
+                self.countOccurrence(refIndex + self.refSeqStart, bytes([refChar]), bytes([readChar]), read.isReverse,
+                                     baseQual, readIndex + 1)
 
     cdef int scanRead(self, cAlignedRead* read) noexcept nogil:
         """variant.pyx:367-474, the part that needs no Python object: the matches' mismatches.  Returns 1 if
@@ -309,15 +353,21 @@ cdef class VariantCandidateGenerator:
                 if flanked and readOffset + length <= read.rlen:
                     inserted = bytes(read.seq[readOffset:readOffset + length])
                     if inserted.count(b"N") == 0:
-                        self.addVariantToList(Variant(self.rname, readStart + refOffset - 1, b"", inserted, 1, nFwd,
-                                                      mapQ, read.qual[readOffset], readOffset + 1))
+                        self.countOccurrence(readStart + refOffset - 1, b"", inserted, read.isReverse, read.qual[readOffset],
+                                             readOffset + 1)
                 readOffset += length
             elif flag == 2:                                                # deletion
                 if flanked and readOffset < read.rlen:
-                    deleted = self.refFile.getSequence(self.rname, readStart + refOffset, readStart + refOffset + length)
-                    if deleted.count(b"N") == 0 and self.genIndels:
-                        self.addVariantToList(Variant(self.rname, readStart + refOffset - 1, deleted, b"", 1, nFwd,
-                                                      mapQ, read.qual[readOffset], readOffset + 1))
+                    where = (readStart + refOffset, length)
+                    deleted = self.deletedSeq.get(where, self)               # (self: not asked for yet)
+                    if deleted is self:
+                        deleted = self.refFile.getSequence(self.rname, readStart + refOffset, readStart + refOffset + length)
+                        if deleted.count(b"N") != 0:
+                            deleted = None
+                        self.deletedSeq[where] = deleted
+                    if deleted is not None and self.genIndels:
+                        self.countOccurrence(readStart + refOffset - 1, deleted, b"", read.isReverse, read.qual[readOffset],
+                                             readOffset + 1)
                 refOffset += length
             elif flag == 0:                                                # match
                 if length >= self.minFlank and self.genSNPs:
@@ -365,6 +415,16 @@ cdef class VariantCandidateGenerator:
         cdef Variant v
         cdef int k
         cdef SnpSums* acc
+        for key, k in self.objIndex.items():               # in the order their first occurrence was met
+            acc = &self.objSums[k]
+            v = Variant(self.rname, key[0], key[1], key[2], acc.n, acc.fwd, 0, 0, 0)
+            v.sumSqReadPos = acc.sumSq
+            v.rmsReadPos = sqrt(<double>(v.sumSqReadPos // acc.n))
+            v.nFwdReadsWeighted = acc.fwdW
+            v.nRevReadsWeighted = acc.revW
+            self.addVariantToList(v)
+        self.objIndex = {}
+        self.nObjSums = 0
         for k in range(self.nSnpSums):
             acc = &self.snpSums[k]
             slot = <size_t>acc.slot

@@ -307,3 +307,48 @@ def test_compiled_modules_are_not_older_than_their_sources():
         ext = bc._ext_path(mod)
         if os.path.exists(ext):
             assert os.path.getmtime(ext) >= os.path.getmtime(bc._source(bc.HERE, mod)), mod
+
+
+def test_standard_form_equals_the_literal_restatement_on_random_indels():
+    """the product compares base by base from the variant leftwards; the restatement builds the mutated sequence over
+    the whole window as the reference does (chaplotype.pyx:532-665): the same standard forms for insertions and
+    deletions in and around repeats, at the sequence's ends, of every length up to 40"""
+    import numpy as np
+    from oracle import candidates_oracle as co
+    from oracle.vcf_oracle import Ref
+    rng = np.random.default_rng(12)
+    units = [b"A", b"AC", b"ACG", b"TTG", b"CAGT", b"GATTACA"]
+    bits = []
+    for k in range(400):
+        bits.append(bytes(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, int(rng.integers(5, 60)))]))
+        u = units[int(rng.integers(0, len(units)))]
+        bits.append(u * int(rng.integers(1, 25)))
+    ref = b"".join(bits)
+    fa, oref = FastaFile(sequences={b"c": ref}), Ref({b"c": ref})
+    n = 0
+    for k in range(3000):
+        pos = int(rng.integers(0, len(ref) - 1))
+        if rng.random() < 0.1:
+            pos = int(rng.choice([0, 1, 50, 99, 100, 101, len(ref) - 2, len(ref) - 41, len(ref) - 3]))
+        size = int(rng.integers(1, 41))
+        if rng.random() < 0.5:
+            # an insertion that copies what follows or precedes it (so that it can move), or random bases
+            src = ref[pos + 1:pos + 1 + size] if rng.random() < 0.6 else bytes(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size)])
+            if not src:
+                continue
+            v = Variant(b"c", pos, b"", src, 2, 1, 60, 30, 7)
+        else:
+            rem = ref[pos + 1:pos + 1 + size]
+            if not rem:
+                continue
+            v = Variant(b"c", pos, rem, b"", 2, 1, 60, 30, 7)
+        try:
+            want = co.standard_format(co.new_variant(b"c", v.refPos, v.removed, v.added, 2, 1, 60, 30, 7), oref)
+        except Exception as e:                          # what the restatement refuses the product refuses
+            with pytest.raises(Exception):
+                pipeline.convertVariantToStandardFormat(v, fa, 150)
+            continue
+        got = pipeline.convertVariantToStandardFormat(v, fa, 150)
+        assert (got.refPos, got.removed, got.added, got.minPos, got.maxPos) == (want.refPos, want.removed, want.added, want.minPos, want.maxPos), (k, v)
+        n += 1
+    assert n > 2500
