@@ -288,14 +288,29 @@ def binomial(x, size, prob):
                     (x * math.log(prob) + (size - x) * math.log(1.0 - prob)))
 
 
-@functools.lru_cache(maxsize=1 << 16)
+_BINOMIAL_SUMS = {}
+
+
 def _binomialSum(upto, size, prob):
     """sum of binomial(i, size, prob) for i = 0..upto, in that order (the p-value sums of
-    cpopulation.pyx:367-386); estimated frequencies repeat (0.5, 1.0, ...), so the sums do too"""
-    total = 0
-    for i in range(upto + 1):
-        total += binomial(i, size, prob)
-    return total
+    cpopulation.pyx:367-386).  Estimated frequencies repeat (0.5, 1.0, ...) and so do coverages, so the running sums
+    of a (size, prob) are kept: a longer sum continues the list, a shorter one reads it -- the same additions in the
+    same order either way."""
+    if upto < 0:
+        return 0
+    key = (size, prob)
+    sums = _BINOMIAL_SUMS.get(key)
+    if sums is None:
+        if len(_BINOMIAL_SUMS) > (1 << 16):
+            _BINOMIAL_SUMS.clear()
+        sums = _BINOMIAL_SUMS[key] = []
+    n = len(sums)
+    if upto >= n:
+        total = sums[-1] if n else 0
+        for i in range(n, upto + 1):
+            total += binomial(i, size, prob)
+            sums.append(total)
+    return sums[upto]
 
 
 def homopolymerLength(variant, refFile):
