@@ -52,8 +52,8 @@ cdef class Population:
                 free(self.genotypePosteriors[index])
             free(self.genotypePosteriors)
         if self.haplotypeIndexes != NULL:
-            for index in range(self.nGenotypes):
-                free(self.haplotypeIndexes[index])
+            if self.nGenotypes > 0:
+                free(self.haplotypeIndexes[0])                 # the rows are one block
             free(self.haplotypeIndexes)
         free(self.frequencies)
         free(self.nReads)
@@ -184,13 +184,7 @@ cdef class Caller:
                 else:
                     pop.genotypeCalls.append(self.genotypes[best[i]])
                     pop.genotypeLikelihoods.append(val[i])
-            g = 0
-            for a in range(nH):
-                for b in range(a, nH):
-                    pop.haplotypeIndexes[g] = <int*>malloc(2 * sizeof(int))
-                    pop.haplotypeIndexes[g][0] = a
-                    pop.haplotypeIndexes[g][1] = b
-                    g += 1
+            fillHaplotypeIndexes(pop.haplotypeIndexes, nH, nG)
         finally:
             free(off); free(best); free(val); free(post)
         return pop
@@ -200,6 +194,24 @@ cdef class Caller:
 
     def callPy(self, int maxIters=100):
         return self.call(maxIters)
+
+
+cdef int fillHaplotypeIndexes(int** rows, int nH, int nG) except -1:
+    """[genotype] -> its two haplotype indexes, the rows cut from one block (freed through rows[0])"""
+    cdef int a, b, g = 0
+    cdef int* block
+    if nG <= 0:
+        return 0
+    block = <int*>malloc(2 * <size_t>nG * sizeof(int))
+    if block == NULL:
+        raise MemoryError()
+    for a in range(nH):
+        for b in range(a, nH):
+            rows[g] = block + 2 * g
+            rows[g][0] = a
+            rows[g][1] = b
+            g += 1
+    return 0
 
 
 cdef Population makePopulation(list haplotypes, list genotypes, list readBuffers, int nI, const int32_t* nReads,
@@ -221,6 +233,7 @@ cdef Population makePopulation(list haplotypes, list genotypes, list readBuffers
     pop.generation = g_generation
     pop.genotypeCalls = []
     pop.genotypeLikelihoods = []
+    cdef dict made = {}
     for i in range(nI):
         pop.nReads[i] = nReads[i]
         if post != NULL:
@@ -230,15 +243,20 @@ cdef Population makePopulation(list haplotypes, list genotypes, list readBuffers
             pop.genotypeCalls.append(None)
             pop.genotypeLikelihoods.append(0.0)
         else:
-            pop.genotypeCalls.append(genotypes[best[i]])
+            if genotypes is not None:
+                pop.genotypeCalls.append(genotypes[best[i]])
+            else:                                         # only the called genotypes are made, once each (cgenotype.pyx:90-96: first index major)
+                gt = made.get(best[i])
+                if gt is None:
+                    a = 0
+                    g = best[i]
+                    while g >= nH - a:
+                        g -= nH - a
+                        a += 1
+                    gt = made[best[i]] = DiploidGenotype(2, [haplotypes[a], haplotypes[a + g]])
+                pop.genotypeCalls.append(gt)
             pop.genotypeLikelihoods.append(val[i])
-    g = 0
-    for a in range(nH):
-        for b in range(a, nH):
-            pop.haplotypeIndexes[g] = <int*>malloc(2 * sizeof(int))
-            pop.haplotypeIndexes[g][0] = a
-            pop.haplotypeIndexes[g][1] = b
-            g += 1
+    fillHaplotypeIndexes(pop.haplotypeIndexes, nH, nG)
     return pop
 
 
@@ -510,8 +528,7 @@ cdef class WindowBatch:
             hi = 0; ii = 0; ci = 0
             for w in range(nW):
                 haps, bufs, counts, firsts = self.windows[w]
-                gts = generateAllGenotypesFromHaplotypeList(2, haps)
-                out.append(makePopulation(haps, gts, bufs, len(bufs), nreads + ii, freq + hi, post + ci if keepPosteriors else NULL,
+                out.append(makePopulation(haps, None, bufs, len(bufs), nreads + ii, freq + hi, post + ci if keepPosteriors else NULL,
                                           best + ii, val + ii, iters[w], change[w], w))
                 hi += len(haps)
                 ii += len(bufs)
