@@ -936,10 +936,15 @@ int pg_align_window(pg_ctx* c, int n_haps, const char* hap_seq, const int64_t* h
         return rc;
     }
     PG_HIP(c, hipSetDevice(c->device));
-    // ---- the block: what the host fills (up to `in_bytes`), what the kernels make, the results ----
+    // ---- the block: the results, the flags, what the host fills, what the kernels make ----
     size_t at = 0;
     auto take = [&](size_t bytes) { const size_t o = at; at += (bytes + 15) & ~(size_t)15; return o; };
     const int n_waves = wave_bound(uniform, max_rlen, np);
+    // results first, then the flags, then what the host fills: one copy takes [flags .. end of the host's part] up (the
+    // flags cleared), one copy brings [results .. flags] back
+    const size_t o_res = at;
+    const size_t o_score = take(4 * (size_t)np), o_anchor = take(4 * (size_t)np), o_like = take(8 * (size_t)np), o_flags = take(64);
+    const size_t res_bytes = at - o_res;
     const size_t o_soff = take(8 * ((size_t)n_haps + 1)), o_doff = take(8 * ((size_t)n_haps + 1)), o_h2off = take(8 * ((size_t)n_haps + 1));
     const size_t o_hlen = take(4 * (size_t)n_haps), o_hstart = take(4 * (size_t)n_haps), o_hvar = take(4 * (size_t)n_haps), o_hord = take(4 * (size_t)n_haps);
     const size_t o_vh = take(sizeof(pg::VoteHap) * ((size_t)n_vote + 1)), o_hcnt = take(4 * ((size_t)n_vote + 1));
@@ -948,7 +953,7 @@ int pg_align_window(pg_ctx* c, int n_haps, const char* hap_seq, const int64_t* h
     const size_t o_status = take(4 * pg::ST_WORDS);
     const size_t o_order = take(uniform ? 0 : 4 * (size_t)np), o_waves = take(uniform ? 0 : sizeof(pg::WaveDesc) * ((size_t)n_waves + 1));
     const size_t o_hraw = take((size_t)hap_total + 16), o_rseq = take((size_t)read_total + 64), o_rqual = take((size_t)read_total + 64);
-    const size_t in_bytes = at;
+    const size_t in_end = at;
     // row offsets (the same as pg_haps_upload and k_read_meta make)
     std::vector<int64_t>& h2 = c->win_tmp;
     h2.assign((size_t)n_haps + n_reads + 2, 0);
@@ -961,12 +966,10 @@ int pg_align_window(pg_ctx* c, int n_haps, const char* hap_seq, const int64_t* h
     const size_t o_readx = take(2 * (size_t)x_read), o_read2 = take(4 * ((size_t)read2off[n_reads] + 16));
     const size_t o_ph = take(4 * (size_t)np), o_pr = take(4 * (size_t)np), o_recs = take(sizeof(pg::VoteRec) * ((size_t)n_vote * n_reads + 1));
     const size_t o_ain = take(4 * (size_t)np);
-    const size_t o_res = at;
-    const size_t o_score = take(4 * (size_t)np), o_anchor = take(4 * (size_t)np), o_like = take(8 * (size_t)np), o_flags = take(64);
-    const size_t res_bytes = at - o_res, total_bytes = at;
-    if (c->h_win_cap < in_bytes + res_bytes) {
+    const size_t total_bytes = at;
+    if (c->h_win_cap < in_end) {
         if (c->h_win) { PG_HIP(c, hipHostFree(c->h_win)); c->h_win = nullptr; c->h_win_cap = 0; }
-        const size_t want = (in_bytes + res_bytes) * 2 + 4096;
+        const size_t want = in_end * 2 + 4096;
         PG_HIP(c, hipHostMalloc((void**)&c->h_win, want, hipHostMallocDefault));
         c->h_win_cap = want;
     }
@@ -1024,8 +1027,8 @@ int pg_align_window(pg_ctx* c, int n_haps, const char* hap_seq, const int64_t* h
         std::memcpy(H + o_rqual, qual + off[0], (size_t)read_total);
     }
     if (x_read < xo + 64) return fail(c, PG_ERR_HIP, "pg_align_window: element rows larger than their bound");
-    PG_HIP(c, hipMemcpyAsync(D, H, in_bytes, hipMemcpyHostToDevice, c->stream));
-    PG_HIP(c, hipMemsetAsync(D + o_flags, 0, 64, c->stream));
+    std::memset(H + o_flags, 0, 64);
+    PG_HIP(c, hipMemcpyAsync(D + o_flags, H + o_flags, in_end - o_flags, hipMemcpyHostToDevice, c->stream));
     pg::WindowArgs A;
     A.n_haps = n_haps; A.n_reads = n_reads; A.n_vote_haps = n_vote; A.pad = pad; A.cap = (int)c->table.size() - 1;
     A.hap_raw = D + o_hraw; A.hap_soff = (const int64_t*)(D + o_soff); A.hap_doff = (const int64_t*)(D + o_doff);
@@ -1053,7 +1056,7 @@ int pg_align_window(pg_ctx* c, int n_haps, const char* hap_seq, const int64_t* h
     W.recs = A.recs; W.anchor_in = (int32_t*)(D + o_ain);
     int rc = enqueue_align(c, U, W, A.pair_hap, A.pair_read, np, (int32_t*)(D + o_score), (int32_t*)(D + o_anchor), (double*)(D + o_like));
     if (rc != PG_OK) { (void)hipStreamSynchronize(c->stream); return rc; }
-    uint8_t* R = H + in_bytes;                            // the results' place in the host block
+    uint8_t* R = H + o_res;                               // the results' place in the host block
     PG_HIP(c, hipMemcpyAsync(R, D + o_res, res_bytes, hipMemcpyDeviceToHost, c->stream));
     PG_HIP(c, hipStreamSynchronize(c->stream));
     const int32_t flags = *(const int32_t*)(R + (o_flags - o_res));
