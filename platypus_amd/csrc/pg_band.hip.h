@@ -31,18 +31,19 @@ __device__ __forceinline__ uint32_t lane_down(uint32_t old, uint32_t v) {    // 
 
 struct BandLane {
     uint32_t m1, i1, d1, m2, i2, d2;
-    uint32_t e2;        // read window: element of read position t - k (bit 0 set: before the read, matches nothing)
-    uint32_t h1;        // haplotype window: word of slice position t + k (even half-step), t + 1 + k (odd)
+    uint32_t e2;        // read window: code | quality << 16 of read position t - k
+    uint32_t h1;        // haplotype window: code of slice position t + k (even half-step), t + 1 + k (odd)
     uint32_t g;         // gap-open window (align.c:100,185-187: it moves the other way)
     uint32_t cr, ch, cg;   // chunks: the next eight entries of the three windows
     uint32_t best;
 };
 
-// cost of align.c:158-162 with the 'N' limit of align.c:68,183
+// cost of align.c:158-162 with the 'N' limit of align.c:68,183, on the codes of pg_align.hip.h (SeqCodes): the read
+// window holds code | quality << 16, the haplotype window the column's code; code & code is 0 for equal bases, at least
+// 128 -- more than any quality -- for different ones and 1 for an 'N' column past the first eight under a read base
+// that is no 'N'
 __device__ __forceinline__ uint32_t band_cost(uint32_t e2, uint32_t q2, uint32_t h1) {
-    const uint32_t x = (e2 ^ h1) & 0x1ffu;
-    const uint32_t c = x == 0 ? 0u : q2;
-    return min(c, (h1 >> 16) & 0xffu);
+    return min(e2 & h1, q2);
 }
 
 // iteration t of align.c:106-232 for lane k of a pair
@@ -55,7 +56,7 @@ __device__ __forceinline__ void band_iter(BandLane& L, int t, int k, int len2, u
     const uint32_t e2_up = lane_up(L.e2, L.e2);
     L.e2 = first ? L.cr : e2_up;
     L.cr = lane_down(L.cr, L.cr);
-    const uint32_t q2 = L.e2 >> 9;
+    const uint32_t q2 = L.e2 >> 16;
     if (EDGE) { L.m1 = k == t ? 0u : L.m1; L.m2 = k == t ? 0u : L.m2; }   // align.c:127-128
     // ---- even half-step, align.c:129-173 ----
     L.m1 = min(L.m1, min(L.i1, L.d1));
@@ -85,9 +86,13 @@ __device__ __forceinline__ void band_iter(BandLane& L, int t, int k, int len2, u
 __global__ __launch_bounds__(64) void k_align_band(const Align2Args A, const int32_t* __restrict__ read_len)
 {
     __shared__ uint8_t s_tab[256];
+    __shared__ uint16_t s_read[256], s_hap[256], s_hap0[256];
     if (A.status[0] != 0x7fffffff) return;                 // the pair list holds an index out of range: nothing is written
     const int lane = threadIdx.x, k = lane & 7, grp = lane >> 3;
-    for (int i = lane; i < 256; i += 64) s_tab[i] = A.tab[i];
+    for (int i = lane; i < 256; i += 64) {
+        s_tab[i] = A.tab[i];
+        s_read[i] = A.codes->read[i]; s_hap[i] = A.codes->hap[i]; s_hap0[i] = A.codes->hap0[i];
+    }
     const int first_pair = blockIdx.x * 8;
     const bool active = first_pair + grp < A.n_pairs;
     const int pair = active ? first_pair + grp : A.n_pairs - 1;
@@ -138,26 +143,29 @@ __global__ __launch_bounds__(64) void k_align_band(const Align2Args A, const int
         const int room = e - pos;
         return (uint32_t)s_tab[min(he >> 9, (uint32_t)(room > 0 ? room : 0))];
     };
-    auto column = [&](uint32_t he, bool n_limit) {                                    // align.c:68,183
-        return (he & 0x1feu) | ((n_limit && (he & 0x1feu) == ((uint32_t)'N' << 1) ? 1u : 255u) << 16);
+    auto read_entry = [&](uint32_t re) {                                              // code | quality << 16
+        return (uint32_t)s_read[(re >> 1) & 0xffu] | ((re >> 9) << 16);
     };
     BandLane L;
     L.m1 = L.i1 = L.d1 = L.m2 = L.i2 = L.d2 = kInf;                                   // align.c:53-58
-    L.e2 = (64u << 9) | 1u;                                                           // align.c:64-65
+    L.e2 = kS2Init | (64u << 16);                                                     // align.c:64-65
     {
         const uint32_t he = hx[k];
-        L.h1 = column(he, false);                                                     // align.c:63,68: no 'N' limit in the first eight columns
+        L.h1 = s_hap0[(he >> 1) & 0xffu];                                             // align.c:63,68: no 'N' limit in the first eight columns
         L.g = gap_open(he, k);                                                        // align.c:100
     }
     L.best = kInf;                                                                    // align.c:34
     Raw n0 = fetch(0), n1 = fetch(8);
-    uint32_t g_next = gap_open(n0.hg, 8 + k);
-    auto take = [&](int t0) {          // block t0 starts: its chunks from n0, the block after next is asked for
-        L.cr = n0.r;
-        L.ch = column(n0.hc, true);
+    // what the table look-ups make of a block's raw entries, one block ahead of its use
+    uint32_t g_next = gap_open(n0.hg, 8 + k), r_next = read_entry(n0.r), h_next = s_hap[(n0.hc >> 1) & 0xffu];
+    auto take = [&](int t0) {          // block t0 starts: its chunks are ready, the next block's are looked up, the one after is asked for
+        L.cr = r_next;
+        L.ch = h_next;
         L.cg = g_next;
         n0 = n1;
         g_next = gap_open(n0.hg, 8 + t0 + 8 + k);
+        r_next = read_entry(n0.r);
+        h_next = s_hap[(n0.hc >> 1) & 0xffu];
         n1 = fetch(t0 + 16);
     };
     int t0 = 0;
