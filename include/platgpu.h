@@ -105,6 +105,9 @@ int pg_set_params(pg_ctx *ctx, int gapextend, int nucprior, const char *table, i
  *   "vote_kernel"    table | bits          anchoring by a 16384-entry position table per haplotype in LDS, or by exact
  *                                          bit-parallel counts for candidate positions (the default for reads of up to
  *                                          263 bases; longer reads always take the table)
+ *   "align_kernel"   lane | band           the banded DP with one lane per pair, or with eight lanes per pair as the
+ *                                          reference's 8 x int16 vectors have it (the default for launches of up to
+ *                                          16384 pairs, whose few wavefronts then finish in a third of the time)
  *   "align_lds_pad"  bytes of unused LDS per workgroup of the DP kernel (lowers occupancy)
  * The process environment is never consulted.
  */
