@@ -16,7 +16,7 @@ path and are not mirrored.
 from libc.stdint cimport int32_t, int64_t, uint8_t
 from libc.stdlib cimport malloc, calloc, free
 from libc.string cimport memcpy, memset
-from libc.math cimport exp
+from libc.math cimport exp, floor
 import time
 
 from platypus_amd.calign cimport deviceContext, ensureReadLength
@@ -196,6 +196,13 @@ cdef class Caller:
         return self.call(maxIters)
 
 
+cdef inline long roundHalfUp(double x) noexcept:
+    """round() of the Python 2 the reference runs on (halves away from zero), for x >= 0; the fraction x - floor(x) is
+    exact, x + 0.5 would not always be"""
+    cdef double r = floor(x)
+    return <long>r + 1 if x - r >= 0.5 else <long>r
+
+
 cdef int fillHaplotypeIndexes(int** rows, int nH, int nG) except -1:
     """[genotype] -> its two haplotype indexes, the rows cut from one block (freed through rows[0])"""
     cdef int a, b, g = 0
@@ -369,6 +376,63 @@ cdef class WindowBatch:
                                 mn = rd.qual[k]
                         mins.append(mn)
         return tc, tcr, tc - tcr, wr, wf, mins
+
+    def siteInfo(self, int w, variant, double freq, refFile, int badReadsWindow, list minQuals, list fwdWeight, binomialSum):
+        """The INFO statistics of one variant (cpopulation.pyx:239-389, chaplotype.pyx:366-432) in one typed pass:
+        (TC, TCR, TCF, HP, SC, RMP, MMLQ, FPV, RPV, ABPV), the three p-values as their '%1.2e' texts.  `minQuals` and
+        `fwdWeight` are the window's running list of minimum base qualities and its running weighted forward coverage:
+        the reference never clears the first between the variants of a window (cpopulation.pyx:231,310) and resets the
+        second under a misspelt name (cpopulation.pyx:269), so both carry over here as they do there.  `binomialSum(upto,
+        size, prob)` is the caller's sum of binomial terms.  The reference sequence around the variant is read from the
+        file's cache where the request lies inside it (fastafile.pyx:148-150), through getSequence otherwise."""
+        cdef int refPos = variant.refPos, tc, tcr, tcf, nl, nr, n, hp, lo, hi
+        cdef double wr, wf, nw, fwdW = variant.nFwdReadsWeighted, revW = variant.nRevReadsWeighted, p
+        cdef bytes added = variant.added, seq, left, right
+        cdef const unsigned char* c
+        cdef Py_ssize_t cacheBegin, cacheEnd, a
+        tc, tcr, tcf, wr, wf, mins = self.siteStatistics(w, refPos, added, badReadsWindow)
+        fwdWeight[0] += wf
+        wf = fwdWeight[0]
+        if mins:
+            minQuals.extend(mins)
+            minQuals.sort()
+        med = minQuals[len(minQuals) // 2] if minQuals else 100
+        # homopolymer run touching the position (chaplotype.pyx:366-402) and the 21 bases around it
+        cache = refFile._cache
+        if (cache is not None and cache[0] == variant.refName and refPos - 20 >= cache[1] and refPos + 21 < cache[2]):
+            seq = cache[3]
+            cacheBegin = cache[1]
+            c = <const unsigned char*>seq
+            a = refPos - cacheBegin                                   # index of the variant's position
+            nl = 1                                                    # bases equal to the one just left of it, leftwards (20 at most)
+            while nl < 20 and c[a - 1 - nl] == c[a - 1]:
+                nl += 1
+            nr = 1
+            while nr < 20 and c[a + 1 + nr] == c[a + 1]:
+                nr += 1
+            hp = max(nl, nr) if c[a - 1] != c[a + 1] else nl + nr
+            sc = seq[a - 10:a + 11]
+        else:
+            left = refFile.getSequence(variant.refName, refPos - 20, refPos)
+            right = refFile.getSequence(variant.refName, refPos + 1, refPos + 21)
+            if len(left) == 0 or len(right) == 0:
+                hp = 0
+            else:
+                nl = <int>(len(left) - len(left.rstrip(left[-1:])))
+                nr = <int>(len(right) - len(right.lstrip(right[:1])))
+                hp = max(nl, nr) if left[-1:] != right[:1] else nl + nr
+            sc = refFile.getSequence(variant.refName, refPos - 10, refPos + 11)
+        nw = fwdW + revW
+        if tc > 0 and nw / <double>tc >= freq / 2.0:                  # cpopulation.pyx:367-373
+            ab = 1.0
+        else:
+            ab = binomialSum(roundHalfUp(nw), tc, freq / 2.0)
+        p = freq if freq < 0.99 else 0.99
+        fwd = binomialSum(roundHalfUp(fwdW), roundHalfUp(wf), p)
+        rev = binomialSum(roundHalfUp(revW), roundHalfUp(wr), p)
+        return (tc, tcr, tcf, hp, sc, round(variant.rmsReadPos, 2),
+                med if (variant.nAdded == 1 and variant.nRemoved == 1) else None,
+                "%1.2e" % fwd, "%1.2e" % rev, "%1.2e" % ab)
 
     def readCounts(self, int w):
         """reads per individual of window w"""

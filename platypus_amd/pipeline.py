@@ -330,25 +330,9 @@ def siteStatistics(batch, k, variant, freq, refFile, options, minQuals, fwdWeigh
     of a window (cpopulation.pyx:231,310), so neither is it cleared here.  `fwdWeight` (a one-element list)
     is the window's running weighted forward coverage: the reference resets it under a misspelt name
     (cpopulation.pyx:269), so every variant's forward p-value sees the sum over the variants before it too."""
-    tc, tcr, tcf, wr, wf, mins = batch.siteStatistics(k, variant.refPos, variant.added, options.badReadsWindow)
-    fwdWeight[0] += wf
-    wf = fwdWeight[0]
-    minQuals.extend(mins)
-    minQuals.sort()
-    med = minQuals[len(minQuals) // 2] if minQuals else 100
-    out = dict(TC=tc, TCR=tcr, TCF=tcf, HP=homopolymerLength(variant, refFile),
-               SC=refFile.getSequence(variant.refName, variant.refPos - 10, variant.refPos + 11),
-               RMP=round(variant.rmsReadPos, 2), MMLQ=med if (variant.nAdded == 1 and variant.nRemoved == 1) else None)
-    nw = variant.nFwdReadsWeighted + variant.nRevReadsWeighted
-    if tc > 0 and nw / float(tc) >= freq / 2.0:                       # cpopulation.pyx:367-373
-        ab = 1.0
-    else:
-        ab = _binomialSum(_round_half_up(nw), tc, freq / 2.0)
-    p = min(0.99, freq)
-    fwd = _binomialSum(_round_half_up(variant.nFwdReadsWeighted), _round_half_up(wf), p)
-    rev = _binomialSum(_round_half_up(variant.nRevReadsWeighted), _round_half_up(wr), p)
-    out.update(FPV="%1.2e" % fwd, RPV="%1.2e" % rev, ABPV="%1.2e" % ab)
-    return out
+    tc, tcr, tcf, hp, sc, rmp, mmlq, fpv, rpv, abpv = batch.siteInfo(k, variant, freq, refFile, options.badReadsWindow,
+                                                                     minQuals, fwdWeight, _binomialSum)
+    return dict(TC=tc, TCR=tcr, TCF=tcf, HP=hp, SC=sc, RMP=rmp, MMLQ=mmlq, FPV=fpv, RPV=rpv, ABPV=abpv)
 
 
 def windowFilters(stats_by_variant, options):
