@@ -413,10 +413,15 @@ def main():
             try:
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import time_stream
-                streamed = time_stream.measure(W=n_windows, N=48, pinned=True, device=device, batch=batch, threads=4)
+                streamed = time_stream.measure(W=n_windows, N=48, pinned=True, device=device, batch=batch, threads=4, built=True)
                 streamed["link_gbps"] = time_stream.link_rate()
-                streamed["what"] = ("haplotypes, reads and window blocks uploaded, kernels run, score / anchor / likelihood "
-                                    "fetched for every batch; bytes_up / link_gbps is the least a batch can take")
+                streamed["what"] = ("haplotypes (as reference stretches and variant lists, put together on the device), reads and "
+                                    "window blocks uploaded, kernels run, score / anchor / likelihood fetched for every batch; "
+                                    "bytes_up / link_gbps is the least a batch can take")
+                whole = time_stream.measure(W=n_windows, N=48, pinned=True, device=device, batch=batch, threads=4)
+                streamed["with_whole_haplotype_sequences"] = {k: whole[k] for k in ("ms_per_batch", "gcups", "bytes_up", "upload_gbps")}
+                # both ways leave the same results on the host
+                streamed["results_equal_both_ways"] = bool(streamed.pop("checksum") == whole.pop("checksum"))
             except Exception as e:                             # reported, never hidden
                 streamed = {"error": "%s: %s" % (type(e).__name__, e)}
         extras["pcie_inclusive"] = streamed

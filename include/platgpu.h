@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 6
+#define PG_ABI_VERSION 7
 
 enum {
     PG_OK = 0,
@@ -129,6 +129,46 @@ int pg_set_option(pg_ctx *ctx, const char *name, const char *value);
  */
 int pg_haps_upload(pg_ctx *ctx, int n, const char *seq, const int64_t *offsets,
                    const int32_t *start_pos, const int32_t *var_seq_len);
+
+/*
+ * The same batch of haplotypes put together on the device from reference
+ * stretches and variant lists: what the reference's constructor does on the host,
+ * one haplotype at a time (platypus/chaplotype.pyx:50-86 through
+ * getMutatedSequence, platypus/chaplotype.pyx:283-353).  A window's stretch goes up
+ * once and every haplotype of it costs its variants only, instead of a whole
+ * sequence each.
+ *   stretch s   ref_seq[ref_off[s] .. ref_off[s+1]) holds the reference bases of
+ *               positions ref_start[s] .. ref_start[s] + length: the padded,
+ *               clamped bounds [startPos, endPos) of platypus/chaplotype.pyx:70-71,
+ *               as refFile.getSequence returns them
+ *   haplotype i stretch hap_stretch[i] with the variants
+ *               [hap_var_off[i], hap_var_off[i+1]) applied, which must be in the
+ *               sorted order the reference's constructor is given them in
+ *   variant v   refPos var_pos[v], nRemoved var_n_removed[v], added sequence
+ *               var_added[var_added_off[v] .. var_added_off[v+1]) (nAdded is its
+ *               length): substitutions (nAdded == nRemoved), deletions
+ *               (nAdded == 0; refPos is the base before the deleted ones) and
+ *               insertions (nRemoved == 0; after the base at refPos), anything else
+ *               is PG_ERR_UNSUPPORTED (the reference's ValueError,
+ *               platypus/chaplotype.pyx:340-342)
+ * Afterwards the context holds what pg_haps_upload leaves for the sequences
+ * getMutatedSequence returns, start_pos = ref_start[hap_stretch[i]] and
+ * var_seq_len = the sum of |nAdded - nRemoved| over the haplotype's variants
+ * (platypus/chaplotype.pyx:66-67); the same limits and errors apply.  A variant
+ * that reaches outside its stretch is PG_ERR_INVALID.  At most 2^31 - 1 bytes
+ * of stretches per call.
+ */
+int pg_haps_build(pg_ctx *ctx, int n_stretches, const char *ref_seq, const int64_t *ref_off, const int32_t *ref_start,
+                  int n_haps, const int32_t *hap_stretch, const int32_t *hap_var_off, const int32_t *var_pos,
+                  const int32_t *var_n_removed, const int32_t *var_added_off, const char *var_added);
+
+/*
+ * The sequences of the context's haplotype batch back on the host (synchronises):
+ * n + 1 offsets starting at 0 and the bytes, Haplotype.haplotypeSequence of
+ * platypus/chaplotype.pyx:78 for haplotypes made by pg_haps_build.  Either output
+ * may be NULL; ask for the offsets first to size `seq`.
+ */
+int pg_haps_fetch(pg_ctx *ctx, char *seq, int64_t *offsets);
 
 /*
  * Reads of a batch, the five cAlignedRead fields the path uses

@@ -75,6 +75,29 @@ __global__ __launch_bounds__(256) void k_pack_codes(const uint8_t* __restrict__ 
     }
 }
 
+// One piece of a haplotype put together on the device (platypus/chaplotype.pyx:283-353, getMutatedSequence): `len`
+// bytes to offset `dst` of the haplotype, from byte `src` of the reference stretches, or -- src < 0 -- from byte ~src
+// of the variants' added sequences.
+struct HapPiece { int32_t src, dst, len; };
+
+// haplotype i = its pieces [piece_off[i], piece_off[i + 1]) one after the other, at raw + soff[i]; one wavefront each
+__global__ __launch_bounds__(256) void k_build_haps(const uint8_t* __restrict__ ref, const uint8_t* __restrict__ added,
+                                                    const HapPiece* __restrict__ pieces, const int32_t* __restrict__ piece_off,
+                                                    const int64_t* __restrict__ soff, uint8_t* __restrict__ raw, int n_haps)
+{
+    const int wave = (int)((blockIdx.x * 256u + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+    const int n_waves = (int)(gridDim.x * 4u);
+    for (int h = wave; h < n_haps; h += n_waves) {
+        uint8_t* out = raw + soff[h];
+        const int p1 = piece_off[h + 1];
+        for (int p = piece_off[h]; p < p1; ++p) {
+            const HapPiece pc = pieces[p];
+            const uint8_t* from = pc.src >= 0 ? ref + pc.src : added + ~pc.src;
+            for (int j = lane; j < pc.len; j += 64) out[pc.dst + j] = from[j];
+        }
+    }
+}
+
 // the 14 bits of the 7-mer starting at base i of a packed row: a relabelling of
 // the hash of platypus/calign.pyx:81-96 (first base in the low bits instead of
 // the high ones), used for both the table and the look-ups

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <type_traits>
@@ -143,6 +144,10 @@ struct pg_ctx {
     DevBuf<int64_t> d_hap2off;
     DevBuf<int64_t> d_hap_soff, d_hap_doff;
     DevBuf<int32_t> d_hap_len, d_hap_start, d_hap_varlen;
+    int64_t hap_bytes = 0;               // bytes of all sequences in d_hap_raw
+    DevBuf<uint8_t> d_build_ref, d_build_added;   // pg_haps_build: reference stretches, added sequences,
+    DevBuf<pg::HapPiece> d_build_pieces;          // the pieces every haplotype is put together from
+    DevBuf<int32_t> d_build_off;
 
     // reads
     int n_reads = 0;
@@ -528,7 +533,7 @@ int pg_ctx_destroy(pg_ctx* c) {
     c->d_readx.release(); c->d_read_xoff.release(); c->d_hap2.release(); c->d_hapU.release(); c->d_hapUbits.release(); c->d_hap2off.release();
     c->d_read2.release(); c->d_read2off.release();
     c->d_exp_score.release(); c->d_exp_mapq.release();
-    c->d_hap_raw.release();
+    c->d_hap_raw.release(); c->d_build_ref.release(); c->d_build_added.release(); c->d_build_pieces.release(); c->d_build_off.release();
     c->d_hap_soff.release(); c->d_hap_doff.release();
     c->d_hap_len.release(); c->d_hap_start.release(); c->d_hap_varlen.release();
     c->d_rseq.release(); c->d_rqual.release(); c->d_roff.release();
@@ -622,12 +627,14 @@ int pg_set_option(pg_ctx* c, const char* name, const char* value) {
     return PG_OK;
 }
 
-int pg_haps_upload(pg_ctx* c, int n, const char* seq, const int64_t* off,
-                   const int32_t* start_pos, const int32_t* var_seq_len) {
-    if (!c) return PG_ERR_INVALID;
-    if (n < 0 || (n > 0 && (!seq || !off || !start_pos || !var_seq_len)))
-        return fail(c, PG_ERR_INVALID, "pg_haps_upload: bad arguments");
-    PG_HIP(c, hipSetDevice(c->device));
+namespace {
+
+// The haplotype batch of a context from `n` sequences whose bytes `fill` puts on the device at d_hap_raw (sequence i at
+// soff[i] .. soff[i + 1], soff[0] = 0): the element rows with their run lengths (k_pack_hapx: the gap-open table build of
+// platypus/c/align.c:70-96, once per haplotype), the packed bases, and for the indel-bearing ones the rows of unique
+// 7-mer starts.
+int haps_install(pg_ctx* c, int n, const std::vector<int64_t>& soff, const int32_t* start_pos, const int32_t* var_seq_len,
+                 const std::function<int()>& fill) {
     c->n_haps = 0; c->n_pairs = 0; c->launched = false;
     if (n == 0) return PG_OK;
     const int pad = c->max_read_len + 64;
@@ -635,7 +642,7 @@ int pg_haps_upload(pg_ctx* c, int n, const char* seq, const int64_t* off,
     std::vector<int32_t> len(n);
     int maxlen = 0;
     for (int i = 0; i < n; ++i) {
-        const int64_t l = off[i + 1] - off[i];
+        const int64_t l = soff[i + 1] - soff[i];
         if (l < 0 || l > (1 << 30)) return fail(c, PG_ERR_INVALID, "haplotype %d has length %lld", i, (long long)l);
         if (var_seq_len[i] != 0 && l > PG_MAX_HASHED_HAP_LEN)
             return fail(c, PG_ERR_UNSUPPORTED, "haplotype %d with indels is %lld long; the 7-mer anchoring takes < 16384", i, (long long)l);
@@ -644,9 +651,9 @@ int pg_haps_upload(pg_ctx* c, int n, const char* seq, const int64_t* off,
             return fail(c, PG_ERR_UNSUPPORTED, "haplotype %d with indels is only %lld long; at least 15 bases are needed", i, (long long)l);
         len[i] = (int32_t)l;
         maxlen = std::max(maxlen, (int)l);
-        doff[i] = (off[i] - off[0]) + (int64_t)i * pad;
+        doff[i] = soff[i] + (int64_t)i * pad;
     }
-    const int64_t total = off[n] - off[0];
+    const int64_t total = soff[n];
     doff[n] = total + (int64_t)n * pad;
     PG_HIP(c, c->d_hap_raw.reserve((size_t)total + 16));
     PG_HIP(c, c->d_hapx.reserve((size_t)doff[n] + 64));
@@ -655,14 +662,15 @@ int pg_haps_upload(pg_ctx* c, int n, const char* seq, const int64_t* off,
     PG_HIP(c, c->d_hap_len.reserve(n));
     PG_HIP(c, c->d_hap_start.reserve(n));
     PG_HIP(c, c->d_hap_varlen.reserve(n));
-    std::vector<int64_t> soff(n + 1);
-    for (int i = 0; i <= n; ++i) soff[i] = off[i] - off[0];
-    PG_HIP(c, hipMemcpyAsync(c->d_hap_raw.p, seq + off[0], (size_t)total, hipMemcpyHostToDevice, c->stream));
     PG_HIP(c, hipMemcpyAsync(c->d_hap_soff.p, soff.data(), (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
     PG_HIP(c, hipMemcpyAsync(c->d_hap_doff.p, doff.data(), (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
     PG_HIP(c, hipMemcpyAsync(c->d_hap_len.p, len.data(), n * 4, hipMemcpyHostToDevice, c->stream));
     PG_HIP(c, hipMemcpyAsync(c->d_hap_start.p, start_pos, n * 4, hipMemcpyHostToDevice, c->stream));
     PG_HIP(c, hipMemcpyAsync(c->d_hap_varlen.p, var_seq_len, n * 4, hipMemcpyHostToDevice, c->stream));
+    {
+        const int rc = fill();
+        if (rc != PG_OK) return rc;
+    }
     const int cap = (int)c->table.size() - 1;
     const int grid = std::min(n, 65536);
     PG_HIP(c, c->d_flag.reserve(64));
@@ -705,7 +713,123 @@ int pg_haps_upload(pg_ctx* c, int n, const char* seq, const int64_t* off,
     if (bad) return fail(c, PG_ERR_UNSUPPORTED, "a haplotype holds a byte outside 1..31, 33..126");
     c->n_vote_haps = (int)vh.size();
     c->max_hap_len = maxlen;
+    c->hap_bytes = total;
     c->n_haps = n;
+    return PG_OK;
+}
+
+}  // namespace
+
+int pg_haps_upload(pg_ctx* c, int n, const char* seq, const int64_t* off,
+                   const int32_t* start_pos, const int32_t* var_seq_len) {
+    if (!c) return PG_ERR_INVALID;
+    if (n < 0 || (n > 0 && (!seq || !off || !start_pos || !var_seq_len)))
+        return fail(c, PG_ERR_INVALID, "pg_haps_upload: bad arguments");
+    PG_HIP(c, hipSetDevice(c->device));
+    c->n_haps = 0; c->n_pairs = 0; c->launched = false;
+    if (n == 0) return PG_OK;
+    std::vector<int64_t> soff(n + 1);
+    for (int i = 0; i <= n; ++i) soff[i] = off[i] - off[0];
+    return haps_install(c, n, soff, start_pos, var_seq_len, [&]() -> int {
+        PG_HIP(c, hipMemcpyAsync(c->d_hap_raw.p, seq + off[0], (size_t)soff[n], hipMemcpyHostToDevice, c->stream));
+        return PG_OK;
+    });
+}
+
+int pg_haps_build(pg_ctx* c, int n_stretches, const char* ref_seq, const int64_t* ref_off, const int32_t* ref_start,
+                  int n, const int32_t* hap_stretch, const int32_t* hap_var_off, const int32_t* var_pos,
+                  const int32_t* var_n_removed, const int32_t* var_added_off, const char* var_added) {
+    if (!c) return PG_ERR_INVALID;
+    if (n < 0 || n_stretches < 0 || (n > 0 && (n_stretches == 0 || !ref_seq || !ref_off || !ref_start || !hap_stretch || !hap_var_off)))
+        return fail(c, PG_ERR_INVALID, "pg_haps_build: bad arguments");
+    PG_HIP(c, hipSetDevice(c->device));
+    c->n_haps = 0; c->n_pairs = 0; c->launched = false;
+    if (n == 0) return PG_OK;
+    const int64_t ref_total = ref_off[n_stretches] - ref_off[0];
+    if (ref_total < 0 || ref_total > 0x7fffffffLL) return fail(c, PG_ERR_INVALID, "pg_haps_build: the stretches hold %lld bytes; at most 2^31 - 1 are taken", (long long)ref_total);
+    const int n_vars = hap_var_off[n] - hap_var_off[0];
+    if (n_vars < 0 || (n_vars > 0 && (!var_pos || !var_n_removed || !var_added_off)))
+        return fail(c, PG_ERR_INVALID, "pg_haps_build: bad arguments");
+    const int64_t added_total = n_vars > 0 ? (int64_t)var_added_off[hap_var_off[n]] - var_added_off[hap_var_off[0]] : 0;
+    if (added_total < 0 || (added_total > 0 && !var_added)) return fail(c, PG_ERR_INVALID, "pg_haps_build: bad arguments");
+    // The walk of getMutatedSequence (platypus/chaplotype.pyx:283-353) per haplotype, in pieces instead of bytes: which
+    // bytes of the stretch and of the variants' added sequences follow one another.  The pieces go to the device, which
+    // copies the bytes; lengths, varSeqLen (chaplotype.pyx:66-67) and startPos are known here.
+    std::vector<pg::HapPiece> pieces;
+    std::vector<int32_t> piece_off(n + 1), start(n), varlen(n);
+    std::vector<int64_t> soff(n + 1);
+    pieces.reserve((size_t)n + 2 * (size_t)n_vars);
+    soff[0] = 0;
+    const int32_t a0 = n_vars > 0 ? var_added_off[hap_var_off[0]] : 0;
+    for (int i = 0; i < n; ++i) {
+        const int s = hap_stretch[i];
+        if (s < 0 || s >= n_stretches) return fail(c, PG_ERR_INVALID, "haplotype %d names stretch %d of %d", i, s, n_stretches);
+        const int64_t slen = ref_off[s + 1] - ref_off[s];
+        if (slen < 0) return fail(c, PG_ERR_INVALID, "stretch %d has length %lld", s, (long long)slen);
+        const int64_t S = ref_start[s], E = S + slen, base = ref_off[s] - ref_off[0] - S;   // byte of position x: base + x
+        int64_t dst = 0;
+        bool outside = false;
+        auto from_ref = [&](int64_t a, int64_t b) {              // refFile.getSequence(refName, a, b)
+            if (a < S || b < a || b > E) { outside = true; return; }
+            if (b > a) { pieces.push_back({(int32_t)(base + a), (int32_t)dst, (int32_t)(b - a)}); dst += b - a; }
+        };
+        const int v0 = hap_var_off[i], v1 = hap_var_off[i + 1];
+        if (v1 < v0) return fail(c, PG_ERR_INVALID, "pg_haps_build: variant offsets of haplotype %d descend", i);
+        piece_off[i] = (int32_t)pieces.size();
+        int vl = 0;
+        if (v0 == v1) {
+            from_ref(S, E);                                      // chaplotype.pyx:290-291
+        } else {
+            int64_t cur = var_pos[v0];
+            from_ref(S, cur);                                    // chaplotype.pyx:296-297
+            for (int v = v0; v < v1; ++v) {
+                const int64_t pos = var_pos[v];
+                const int nrem = var_n_removed[v], nadd = var_added_off[v + 1] - var_added_off[v];
+                if (nrem < 0 || nadd < 0) return fail(c, PG_ERR_INVALID, "variant %d removes %d and adds %d bases", v, nrem, nadd);
+                vl += std::abs(nadd - nrem);
+                if (pos < S || pos + nrem + (nadd != nrem) > E) { outside = true; break; }   // the bases it names are not in the stretch
+                auto added = [&]() {
+                    if (nadd > 0) { pieces.push_back({~(int32_t)(var_added_off[v] - a0), (int32_t)dst, nadd}); dst += nadd; }
+                };
+                if (pos > cur) { from_ref(cur, pos); cur = pos; }                         // chaplotype.pyx:303-305
+                if (nadd == nrem) { added(); cur += nadd; }                               // chaplotype.pyx:308-310
+                else if (nadd == 0) { if (pos == cur) { from_ref(pos, pos + 1); cur += 1; } cur += nrem; }   // :313-323
+                else if (nrem == 0) { if (pos == cur) { from_ref(pos, pos + 1); cur += 1; } added(); }       // :326-338
+                else return fail(c, PG_ERR_UNSUPPORTED, "variant %d removes %d and adds %d bases: not a substitution, an insertion or a deletion", v, nrem, nadd);   // chaplotype.pyx:340-342
+                if (outside) break;
+            }
+            if (!outside && cur < E) from_ref(cur, E);           // chaplotype.pyx:345-346
+        }
+        if (outside) return fail(c, PG_ERR_INVALID, "haplotype %d: a variant lies outside its stretch %d..%d", i, (int)S, (int)E);
+        start[i] = (int32_t)S;
+        varlen[i] = vl;
+        soff[i + 1] = soff[i] + dst;
+    }
+    piece_off[n] = (int32_t)pieces.size();
+    return haps_install(c, n, soff, start.data(), varlen.data(), [&]() -> int {
+        PG_HIP(c, c->d_build_ref.reserve((size_t)ref_total + 16));
+        PG_HIP(c, c->d_build_added.reserve((size_t)added_total + 16));
+        PG_HIP(c, c->d_build_pieces.reserve(pieces.size() + 1));
+        PG_HIP(c, c->d_build_off.reserve((size_t)n + 1));
+        PG_HIP(c, hipMemcpyAsync(c->d_build_ref.p, ref_seq + ref_off[0], (size_t)ref_total, hipMemcpyHostToDevice, c->stream));
+        if (added_total > 0)
+            PG_HIP(c, hipMemcpyAsync(c->d_build_added.p, var_added + a0, (size_t)added_total, hipMemcpyHostToDevice, c->stream));
+        PG_HIP(c, hipMemcpyAsync(c->d_build_pieces.p, pieces.data(), pieces.size() * sizeof(pg::HapPiece), hipMemcpyHostToDevice, c->stream));
+        PG_HIP(c, hipMemcpyAsync(c->d_build_off.p, piece_off.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(pg::k_build_haps, dim3(std::min((n + 3) / 4, 65536)), dim3(256), 0, c->stream, c->d_build_ref.p,
+                           c->d_build_added.p, c->d_build_pieces.p, c->d_build_off.p, c->d_hap_soff.p, c->d_hap_raw.p, n);
+        PG_HIP(c, hipGetLastError());
+        return PG_OK;
+    });
+}
+
+int pg_haps_fetch(pg_ctx* c, char* seq, int64_t* offsets) {
+    if (!c) return PG_ERR_INVALID;
+    if (c->n_haps == 0) return fail(c, PG_ERR_STATE, "pg_haps_fetch: no haplotypes on the device");
+    PG_HIP(c, hipSetDevice(c->device));
+    if (offsets) PG_HIP(c, hipMemcpyAsync(offsets, c->d_hap_soff.p, ((size_t)c->n_haps + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    if (seq && c->hap_bytes > 0) PG_HIP(c, hipMemcpyAsync(seq, c->d_hap_raw.p, (size_t)c->hap_bytes, hipMemcpyDeviceToHost, c->stream));
+    PG_HIP(c, hipStreamSynchronize(c->stream));
     return PG_OK;
 }
 

@@ -17,7 +17,7 @@ PG_OK = 0
 PG_ERR_NO_DEVICE, PG_ERR_INVALID, PG_ERR_HIP, PG_ERR_UNSUPPORTED, PG_ERR_STATE = -1, -2, -3, -4, -5
 PG_SCORE_ASSERT_FAILED = -1
 PG_K_ANCHOR, PG_K_ALIGN, PG_K_GENOTYPE, PG_K_CALLER_SETUP, PG_K_CALLER_EM = 0, 1, 2, 3, 4
-ABI_VERSION = 6
+ABI_VERSION = 7
 NOALLOC_MAX_PAIRS, NOALLOC_MAX_INDEL_HAPS = 262144, 65536      # PG_NOALLOC_MAX_* of include/platgpu.h
 
 # every symbol include/platgpu.h declares: (restype, argtypes)
@@ -33,6 +33,8 @@ SYMBOLS = {
     "pg_set_params": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_int]),
     "pg_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
     "pg_haps_upload": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _i64p, _i32p, _i32p]),
+    "pg_haps_build": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _i64p, _i32p, C.c_int, _i32p, _i32p, _i32p, _i32p, _i32p, C.c_void_p]),
+    "pg_haps_fetch": (C.c_int, [C.c_void_p, C.c_void_p, _i64p]),
     "pg_reads_upload": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _i64p, _i32p, _i32p]),
     "pg_pairs_upload": (C.c_int, [C.c_void_p, C.c_int64, _i32p, _i32p]),
     "pg_pairs_block": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -133,6 +135,7 @@ class AlignContext(object):
             raise PlatGpuError(rc, (LIB.pg_last_error_string(None) or b"").decode())
         self._h = h
         self.n_pairs = 0
+        self.n_haps = 0
 
     def close(self):
         if self._h is not None:
@@ -162,6 +165,28 @@ class AlignContext(object):
         seq = _arr(seq, np.uint8); off = _arr(off, np.int64)
         sp = _arr(start_pos, np.int32); vl = _arr(var_seq_len, np.int32)
         self._check(LIB.pg_haps_upload(self._h, len(off) - 1, _ptr(seq), _ptr(off), _ptr(sp), _ptr(vl)))
+        self.n_haps = len(off) - 1
+
+    def build_haps(self, ref_seq, ref_off, ref_start, hap_stretch, hap_var_off, var_pos, var_n_removed, var_added_off,
+                   var_added):
+        """the haplotype batch from reference stretches and variant lists, put together on the device
+        (include/platgpu.h: pg_haps_build)"""
+        rs = _arr(ref_seq, np.uint8); ro = _arr(ref_off, np.int64); st = _arr(ref_start, np.int32)
+        hs = _arr(hap_stretch, np.int32); hv = _arr(hap_var_off, np.int32)
+        vp = _arr(var_pos, np.int32); vr = _arr(var_n_removed, np.int32); vo = _arr(var_added_off, np.int32)
+        va = _arr(var_added, np.uint8)
+        assert len(hv) == len(hs) + 1 and len(st) == len(ro) - 1 and len(vo) == len(vp) + 1 == len(vr) + 1
+        self._check(LIB.pg_haps_build(self._h, len(st), _ptr(rs), _ptr(ro), _ptr(st), len(hs), _ptr(hs), _ptr(hv), _ptr(vp),
+                                      _ptr(vr), _ptr(vo), _ptr(va)))
+        self.n_haps = len(hs)
+
+    def fetch_haps(self):
+        """(sequence bytes, offsets) of the haplotype batch on the device"""
+        off = np.empty(self.n_haps + 1, dtype=np.int64)
+        self._check(LIB.pg_haps_fetch(self._h, None, _ptr(off)))
+        seq = np.empty(int(off[-1]), dtype=np.uint8)
+        self._check(LIB.pg_haps_fetch(self._h, _ptr(seq), None))
+        return seq, off
 
     def upload_reads(self, seq, qual, off, pos, mapq):
         seq = _arr(seq, np.uint8); qual = _arr(qual, np.uint8); off = _arr(off, np.int64)

@@ -19,6 +19,10 @@ cdef extern from "platgpu.h":
                                int32_t* d_score, int32_t* d_anchor, double* d_likelihood)
     int pg_haps_upload(pg_ctx* ctx, int n, const char* seq, const int64_t* offsets,
                        const int32_t* start_pos, const int32_t* var_seq_len)
+    int pg_haps_build(pg_ctx* ctx, int n_stretches, const char* ref_seq, const int64_t* ref_off, const int32_t* ref_start,
+                      int n_haps, const int32_t* hap_stretch, const int32_t* hap_var_off, const int32_t* var_pos,
+                      const int32_t* var_n_removed, const int32_t* var_added_off, const char* var_added)
+    int pg_haps_fetch(pg_ctx* ctx, char* seq, int64_t* offsets)
     int pg_reads_upload(pg_ctx* ctx, int n, const char* seq, const char* qual, const int64_t* offsets,
                         const int32_t* pos, const int32_t* mapq)
     int pg_pairs_upload(pg_ctx* ctx, int64_t n_pairs, const int32_t* hap_idx, const int32_t* read_idx)

@@ -59,6 +59,8 @@ def make_batch(n_windows, haps_per_window=4, reads_per_window=32, read_len=150,
     vpos_all = rng.integers(hap_len // 3, 2 * hap_len // 3, size=W * H)
     vlen_all = rng.integers(1, 7, size=W * H)
     vins_all = rng.random(W * H) < 0.5
+    # the same haplotypes as (window's reference stretch, variant list): what pg_haps_build takes
+    var_hap, var_pos, var_nrem, var_added = [], [], [], []
     for w in range(W):
         b = base[w]
         for h in range(H):
@@ -70,6 +72,7 @@ def make_batch(n_windows, haps_per_window=4, reads_per_window=32, read_len=150,
                 p = vpos_all[i]
                 s[p] = ACGT[(np.searchsorted(ACGT, s[p] if s[p] != 78 else 65) + 1) % 4]
                 hap_vpos[i] = p
+                var_hap.append(i); var_pos.append(int(p)); var_nrem.append(1); var_added.append(s[p:p + 1])
             else:
                 p, n = int(vpos_all[i]), int(vlen_all[i])
                 if homopolymers and rng.random() < 0.5:
@@ -82,9 +85,11 @@ def make_batch(n_windows, haps_per_window=4, reads_per_window=32, read_len=150,
                     ins = np.repeat(b[p], n) if homopolymers else ACGT[rng.integers(0, 4, size=n)]
                     s = np.concatenate([b[:p + 1], ins, b[p + 1:]])
                     hap_delta[i] = n
+                    var_hap.append(i); var_pos.append(p); var_nrem.append(0); var_added.append(ins)
                 else:
                     s = np.concatenate([b[:p + 1], b[p + 1 + n:]])
                     hap_delta[i] = -n
+                    var_hap.append(i); var_pos.append(p); var_nrem.append(n); var_added.append(ACGT[:0])
                 hap_varlen[i] = n
                 hap_vpos[i] = p
             hap_chunks.append(s)
@@ -166,8 +171,19 @@ def make_batch(n_windows, haps_per_window=4, reads_per_window=32, read_len=150,
     pair_read = (np.arange(W, dtype=np.int32)[:, None, None] * R + 0 * hh[None, :, None]
                  + rr[None, None, :]).reshape(-1).astype(np.int32)
 
+    var_hap = np.asarray(var_hap, dtype=np.int64)
+    hap_var_off = np.zeros(W * H + 1, dtype=np.int32)
+    np.cumsum(np.bincount(var_hap, minlength=W * H), out=hap_var_off[1:])
+    var_added_off = np.zeros(len(var_hap) + 1, dtype=np.int32)
+    np.cumsum([len(a) for a in var_added], out=var_added_off[1:])
+    built = dict(ref_seq=base.reshape(-1), ref_off=np.arange(W + 1, dtype=np.int64) * hap_len, ref_start=win_start.astype(np.int32),
+                 hap_stretch=np.repeat(np.arange(W, dtype=np.int32), H), hap_var_off=hap_var_off,
+                 var_pos=(np.asarray(var_pos, dtype=np.int64) + win_start[var_hap // H]).astype(np.int32),
+                 var_n_removed=np.asarray(var_nrem, dtype=np.int32), var_added_off=var_added_off,
+                 var_added=np.concatenate(var_added) if var_added else ACGT[:0])
+
     return dict(hap_seq=hap_seq, hap_off=hap_off, hap_start=hap_start.astype(np.int32),
-                hap_varlen=hap_varlen,
+                hap_varlen=hap_varlen, built=built,
                 read_seq=read_seq, read_qual=read_qual, read_off=read_off,
                 read_pos=read_pos, read_mapq=read_mapq,
                 pair_hap=pair_hap, pair_read=pair_read,
