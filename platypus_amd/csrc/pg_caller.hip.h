@@ -644,6 +644,10 @@ __device__ __forceinline__ double share_load(const double* p) {
 // New frequencies of one window from the individuals' shares (added in individual order), largest change,
 // convergence flag: the work of one workgroup of n_thr threads (at most 16 wavefronts).  s_has: one byte per
 // individual in LDS.
+#ifndef PG_UPDATE_BATCH
+#define PG_UPDATE_BATCH 16
+#endif
+constexpr int kUpdateBatch = PG_UPDATE_BATCH;
 template <bool SAME_LAUNCH>
 __device__ __forceinline__ void em_update_window(const WinDesc& W, const int32_t* __restrict__ io, EmState S, int w,
                                                  int max_iters, int tid, int n_thr, unsigned char* s_has,
@@ -668,15 +672,15 @@ __device__ __forceinline__ void em_update_window(const WinDesc& W, const int32_t
     double ch = 0.0;
     for (int k = tid; k < n; k += n_thr) {
         double t = 0.0;
-        // eight shares are fetched before the first is added (the compiler keeps loads where they
+        // kUpdateBatch shares are fetched before the first is added (the compiler keeps loads where they
         // are written, and fifty dependent load-add steps are fifty memory latencies); the
         // additions stay in individual order
-        for (int i0 = 0; i0 < W.n_ind; i0 += 8) {
-            double v[8];
+        for (int i0 = 0; i0 < W.n_ind; i0 += kUpdateBatch) {
+            double v[kUpdateBatch];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = i0 + j < W.n_ind ? share_load<SAME_LAUNCH>(sh + (int64_t)(i0 + j) * n + k) : 0.0;
+            for (int j = 0; j < kUpdateBatch; ++j) v[j] = i0 + j < W.n_ind ? share_load<SAME_LAUNCH>(sh + (int64_t)(i0 + j) * n + k) : 0.0;
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
+            for (int j = 0; j < kUpdateBatch; ++j)
                 if (i0 + j < W.n_ind && s_has[i0 + j]) t += v[j];             // cpopulation.pyx:869-880, individual order
         }
         const double old = S.f[W.hap_base + k], nf = t / (2 * n_with_data);  // :883
@@ -958,8 +962,9 @@ __global__ __launch_bounds__(512) void k_em_calls(const WinDesc* __restrict__ wi
     const int64_t total = (int64_t)n * (n + 1) / 2, per = (total + n_wav - 1) / n_wav;
     int r0 = n, r1 = n;
     int64_t before = 0;                                                      // elements of the rows above a
+    const int64_t mine_lo = (int64_t)wave * per, mine_hi = mine_lo + per;
     for (int a = 0; a < n; ++a) {                                            // a few hundred rows: every thread walks them
-        if ((int)(before / per) == wave) {
+        if (before >= mine_lo && before < mine_hi) {                         // before / per == wave, without the division
             if (r0 == n) r0 = a;
             r1 = a + 1;
         }
@@ -969,12 +974,31 @@ __global__ __launch_bounds__(512) void k_em_calls(const WinDesc* __restrict__ wi
     const double s = S.csr[W.ind_base + i];
     double bv = 0.0;
     int bj = 0x7fffffff;
-    for (int a = r0; a < r1; ++a) {
-        const int64_t row = tri_row_start(a, n);
-        for (int b = a + lane; b < n; b += 64) {
-            double v = P[(int64_t)a * W.ld + b] * f[a] * f[b] * (1 + (a != b));   // cpopulation.pyx:847
+    // The wavefront's pieces -- 64 consecutive elements of a row, from its diagonal on -- eight at a time: the eight
+    // loads are issued before the first value is used (one piece per step is one memory latency per step).  No load
+    // is conditional: a piece past the range re-reads the last row, a lane past the row's end the row's last element.
+    // A lane meets its genotypes in ascending order, so "larger wins" keeps the first of equal maxima.
+    int a_s = __builtin_amdgcn_readfirstlane(r0), c_s = 0;                   // the piece walk stays in scalar registers
+    const int r1_s = __builtin_amdgcn_readfirstlane(r1);
+    while (a_s < r1_s) {
+        double p[8];
+        int pa[8], pb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int a = min(a_s, r1_s - 1);
+            pa[u] = a_s < r1_s ? a : -1;
+            pb[u] = a + c_s * 64 + lane;
+            p[u] = P[(int64_t)a * W.ld + min(pb[u], n - 1)];
+            ++c_s;
+            if (a_s + c_s * 64 >= n) { ++a_s; c_s = 0; }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int a = pa[u], b = pb[u];
+            if (a < 0 || b >= n) continue;
+            double v = p[u] * f[a] * f[b] * (1 + (a != b));                  // cpopulation.pyx:847
             if (s > 0.0) v /= s;
-            const int j = (int)(row + b - a);
+            const int j = (int)(tri_row_start(a, n) + b - a);
             if (bj == 0x7fffffff || v > bv) { bv = v; bj = j; }             // cpopulation.pyx:791
         }
     }
