@@ -332,6 +332,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-e2e", action="store_true", help="skip the file-to-file end-to-end leg")
     ap.add_argument("--no-stream", action="store_true", help="skip the PCIe-inclusive (streamed batches) leg")
+    ap.add_argument("--stream-threads", type=int, default=4, help="contexts (a host thread each) of the PCIe-inclusive leg")
     ap.add_argument("--e2e-mb", type=float, default=None, help="length of the simulated reference of the end-to-end leg, Mb")
     ap.add_argument("--e2e-workers", type=int, default=4, help="host processes per GPU of the multi-process end-to-end runs")
     ap.add_argument("--dry-run", action="store_true",
@@ -413,12 +414,12 @@ def main():
             try:
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import time_stream
-                streamed = time_stream.measure(W=n_windows, N=48, pinned=True, device=device, batch=batch, threads=4, built=True)
+                streamed = time_stream.measure(W=n_windows, N=48, pinned=True, device=device, batch=batch, threads=args.stream_threads, built=True)
                 streamed["link_gbps"] = time_stream.link_rate()
                 streamed["what"] = ("haplotypes (as reference stretches and variant lists, put together on the device), reads and "
                                     "window blocks uploaded, kernels run, score / anchor / likelihood fetched for every batch; "
                                     "bytes_up / link_gbps is the least a batch can take")
-                whole = time_stream.measure(W=n_windows, N=48, pinned=True, device=device, batch=batch, threads=4)
+                whole = time_stream.measure(W=n_windows, N=48, pinned=True, device=device, batch=batch, threads=args.stream_threads)
                 streamed["with_whole_haplotype_sequences"] = {k: whole[k] for k in ("ms_per_batch", "gcups", "bytes_up", "upload_gbps")}
                 # both ways leave the same results on the host
                 streamed["results_equal_both_ways"] = bool(streamed.pop("checksum") == whole.pop("checksum"))
