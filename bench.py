@@ -332,7 +332,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-e2e", action="store_true", help="skip the file-to-file end-to-end leg")
     ap.add_argument("--no-stream", action="store_true", help="skip the PCIe-inclusive (streamed batches) leg")
-    ap.add_argument("--stream-threads", type=int, default=4, help="contexts (a host thread each) of the PCIe-inclusive leg")
+    ap.add_argument("--stream-threads", type=int, default=6, help="contexts (a host thread each) of the PCIe-inclusive leg")
     ap.add_argument("--e2e-mb", type=float, default=None, help="length of the simulated reference of the end-to-end leg, Mb")
     ap.add_argument("--e2e-workers", type=int, default=4, help="host processes per GPU of the multi-process end-to-end runs")
     ap.add_argument("--dry-run", action="store_true",
@@ -408,7 +408,7 @@ def main():
         roofline_anchor["pairs_counted_over_every_position"] = n_full
         extras["caller_stage"] = caller_stage(ctx, args, n_windows)
         # ---- PCIe-inclusive rate, never `value`: the same batch streamed from page-locked host memory through the
-        # ABI (everything uploaded and fetched per batch, four contexts fed by a host thread each), beside the link's own rate
+        # ABI (everything uploaded and fetched per batch, six contexts fed by a host thread each), beside the link's own rate
         streamed = None
         if world == 1 and not args.no_stream and args.workload == "wgs":
             try:
