@@ -414,15 +414,20 @@ def main():
             try:
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import time_stream
-                streamed = time_stream.measure(W=n_windows, N=48, pinned=True, device=device, batch=batch, threads=args.stream_threads, built=True)
+                streamed = time_stream.measure(W=n_windows, N=48, pinned=True, device=device, batch=batch, threads=args.stream_threads,
+                                               built=True, nibbles=True)
                 streamed["link_gbps"] = time_stream.link_rate()
-                streamed["what"] = ("haplotypes (as reference stretches and variant lists, put together on the device), reads and "
-                                    "window blocks uploaded, kernels run, score / anchor / likelihood fetched for every batch; "
-                                    "bytes_up / link_gbps is the least a batch can take")
-                whole = time_stream.measure(W=n_windows, N=48, pinned=True, device=device, batch=batch, threads=args.stream_threads)
-                streamed["with_whole_haplotype_sequences"] = {k: whole[k] for k in ("ms_per_batch", "gcups", "bytes_up", "upload_gbps")}
-                # both ways leave the same results on the host
-                streamed["results_equal_both_ways"] = bool(streamed.pop("checksum") == whole.pop("checksum"))
+                streamed["what"] = ("haplotypes (as reference stretches and variant lists, put together on the device), reads (bases two "
+                                    "per byte, as a BAM record holds them) and window blocks uploaded, kernels run, score / anchor / "
+                                    "likelihood fetched for every batch; bytes_up / link_gbps is the least a batch can take")
+                # the same stream with the larger forms of the inputs: every way leaves the same results on the host
+                same = True
+                for key, kw in (("with_read_bases_as_characters", dict(built=True)), ("with_whole_haplotype_sequences_too", dict())):
+                    other = time_stream.measure(W=n_windows, N=48, pinned=True, device=device, batch=batch, threads=args.stream_threads, **kw)
+                    same = same and other["checksum"] == streamed["checksum"]
+                    streamed[key] = {k: other[k] for k in ("ms_per_batch", "gcups", "bytes_up", "upload_gbps")}
+                streamed.pop("checksum")
+                streamed["results_equal_every_way"] = bool(same)
             except Exception as e:                             # reported, never hidden
                 streamed = {"error": "%s: %s" % (type(e).__name__, e)}
         extras["pcie_inclusive"] = streamed

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 7
+#define PG_ABI_VERSION 8
 
 enum {
     PG_OK = 0,
@@ -179,6 +179,21 @@ int pg_haps_fetch(pg_ctx *ctx, char *seq, int64_t *offsets);
  */
 int pg_reads_upload(pg_ctx *ctx, int n, const char *seq, const char *qual,
                     const int64_t *offsets, const int32_t *pos, const int32_t *mapq);
+
+/*
+ * The same batch with the bases as a BAM record holds them: two per byte in the
+ * 4-bit code "=ACMGRSVTWYHKDBN" (bam1_seq / bam_nt16_rev_table of the vendored
+ * samtools, platypus/c/samtools/bam.h; what platypus/samtoolsWrapper.pyx turns
+ * into the characters of cAlignedRead.seq one read at a time), the high half of a
+ * byte first.  Base k of the batch is nibble k of seq4 -- read i's base j is nibble
+ * offsets[i] + j, reads follow one another without padding -- so seq4 holds
+ * (offsets[n] + 1) / 2 bytes; qualities, offsets, positions and mapping
+ * qualities as for pg_reads_upload.  The device expands the codes to the same
+ * characters and everything behind that is shared; a batch's bases cost half the
+ * bytes on the way up.
+ */
+int pg_reads_upload_nibbles(pg_ctx *ctx, int n, const uint8_t *seq4, const char *qual,
+                            const int64_t *offsets, const int32_t *pos, const int32_t *mapq);
 
 /*
  * The (haplotype, read) pairs to score, indices into the uploaded batches.

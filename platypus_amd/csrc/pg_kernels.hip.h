@@ -75,6 +75,23 @@ __global__ __launch_bounds__(256) void k_pack_codes(const uint8_t* __restrict__ 
     }
 }
 
+// Bases in BAM's 4-bit code ("=ACMGRSVTWYHKDBN", bam.h: bam_nt16_rev_table; the high half of a byte first) to one byte
+// each: dst[k] = base of nibble first + k of src.  Two bases per thread and pass.
+__global__ __launch_bounds__(256) void k_unpack_nibbles(const uint8_t* __restrict__ src, int first, int64_t n, uint8_t* __restrict__ dst)
+{
+    const uint64_t table_lo = 0x565352474d43413dull, table_hi = 0x4e42444b48595754ull;   // "=ACMGRSV" "TWYHKDBN", first letter in the low byte
+    for (int64_t k = 2 * ((int64_t)blockIdx.x * 256 + threadIdx.x); k < n; k += 2 * (int64_t)gridDim.x * 256) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (k + j >= n) break;
+            const int64_t nib = first + k + j;
+            const uint32_t b = src[nib >> 1];
+            const uint32_t code = (nib & 1) ? (b & 15u) : (b >> 4);
+            dst[k + j] = (uint8_t)((code < 8 ? table_lo >> (8 * code) : table_hi >> (8 * (code - 8))) & 0xffu);
+        }
+    }
+}
+
 // One piece of a haplotype put together on the device (platypus/chaplotype.pyx:283-353, getMutatedSequence): `len`
 // bytes to offset `dst` of the haplotype, from byte `src` of the reference stretches, or -- src < 0 -- from byte ~src
 // of the variants' added sequences.

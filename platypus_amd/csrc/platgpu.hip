@@ -155,6 +155,7 @@ struct pg_ctx {
     bool uniform_rlen = true;
     DevBuf<int32_t> d_read_len;
     DevBuf<uint8_t> d_rseq, d_rqual;
+    DevBuf<uint8_t> d_rseq4;            // pg_reads_upload_nibbles: the bases as they came, two per byte
     DevBuf<uint16_t> d_readx;
     DevBuf<int64_t> d_roff, d_read_xoff, d_read2off, d_off_in, d_scan_tops;
     DevBuf<uint32_t> d_read2;           // 2-bit packed bases
@@ -536,7 +537,7 @@ int pg_ctx_destroy(pg_ctx* c) {
     c->d_hap_raw.release(); c->d_build_ref.release(); c->d_build_added.release(); c->d_build_pieces.release(); c->d_build_off.release();
     c->d_hap_soff.release(); c->d_hap_doff.release();
     c->d_hap_len.release(); c->d_hap_start.release(); c->d_hap_varlen.release();
-    c->d_rseq.release(); c->d_rqual.release(); c->d_roff.release();
+    c->d_rseq.release(); c->d_rseq4.release(); c->d_rqual.release(); c->d_roff.release();
     c->d_read_pos.release(); c->d_read_mapq.release(); c->d_flag.release();
     c->d_pair_hap.release(); c->d_pair_read.release(); c->d_order.release();
     c->d_vh.release(); c->d_anchor_in.release(); c->d_hap_vote_ord.release(); c->d_read_len.release();
@@ -833,11 +834,13 @@ int pg_haps_fetch(pg_ctx* c, char* seq, int64_t* offsets) {
     return PG_OK;
 }
 
-int pg_reads_upload(pg_ctx* c, int n, const char* seq, const char* qual, const int64_t* off,
-                    const int32_t* pos, const int32_t* mapq) {
+namespace {
+// the read batch of a context; nibbles: `seq` holds two bases per byte in BAM's 4-bit code (pg_reads_upload_nibbles)
+int reads_install(pg_ctx* c, int n, const char* seq, const char* qual, const int64_t* off,
+                  const int32_t* pos, const int32_t* mapq, bool nibbles) {
     if (!c) return PG_ERR_INVALID;
     if (n < 0 || (n > 0 && (!seq || !qual || !off || !pos || !mapq)))
-        return fail(c, PG_ERR_INVALID, "pg_reads_upload: bad arguments");
+        return fail(c, PG_ERR_INVALID, "%s: bad arguments", nibbles ? "pg_reads_upload_nibbles" : "pg_reads_upload");
     PG_HIP(c, hipSetDevice(c->device));
     c->n_reads = 0; c->n_pairs = 0; c->launched = false;
     if (n == 0) return PG_OK;
@@ -877,7 +880,15 @@ int pg_reads_upload(pg_ctx* c, int n, const char* seq, const char* qual, const i
         hipLaunchKernelGGL(pg::scan64_add, dim3(nb), dim3(1024), 0, c->stream, a, (int64_t)n, tops);
     }
     PG_HIP(c, hipGetLastError());
-    PG_HIP(c, hipMemcpyAsync(c->d_rseq.p, seq + off[0], (size_t)total, hipMemcpyHostToDevice, c->stream));
+    if (nibbles) {                                     // base k of the batch is nibble off[0] + k of `seq`, the high one first
+        const int64_t first = off[0] >> 1, n_bytes = ((off[n] + 1) >> 1) - first;
+        PG_HIP(c, c->d_rseq4.reserve((size_t)n_bytes + 16));
+        PG_HIP(c, hipMemcpyAsync(c->d_rseq4.p, seq + first, (size_t)n_bytes, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(pg::k_unpack_nibbles, dim3((unsigned)std::min<int64_t>((total + 511) / 512, 65536)), dim3(256), 0, c->stream,
+                           c->d_rseq4.p, (int)(off[0] & 1), total, c->d_rseq.p);
+    } else {
+        PG_HIP(c, hipMemcpyAsync(c->d_rseq.p, seq + off[0], (size_t)total, hipMemcpyHostToDevice, c->stream));
+    }
     PG_HIP(c, hipMemcpyAsync(c->d_rqual.p, qual + off[0], (size_t)total, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(pg::k_pack_readx, dim3(std::min((n + 3) / 4, 65536)), dim3(256), 0, c->stream, c->d_rseq.p,
                        c->d_rqual.p, c->d_roff.p, c->d_read_xoff.p, c->d_readx.p, c->d_codes.p, n, c->d_flag.p);
@@ -899,6 +910,17 @@ int pg_reads_upload(pg_ctx* c, int n, const char* seq, const char* qual, const i
     c->uniform_rlen = (st[9] == st[10]);
     c->n_reads = n;
     return PG_OK;
+}
+}  // namespace
+
+int pg_reads_upload(pg_ctx* c, int n, const char* seq, const char* qual, const int64_t* off,
+                    const int32_t* pos, const int32_t* mapq) {
+    return reads_install(c, n, seq, qual, off, pos, mapq, false);
+}
+
+int pg_reads_upload_nibbles(pg_ctx* c, int n, const uint8_t* seq4, const char* qual, const int64_t* off,
+                            const int32_t* pos, const int32_t* mapq) {
+    return reads_install(c, n, reinterpret_cast<const char*>(seq4), qual, off, pos, mapq, true);
 }
 
 int pg_pairs_upload(pg_ctx* c, int64_t np, const int32_t* hap_idx, const int32_t* read_idx) {

@@ -17,7 +17,7 @@ PG_OK = 0
 PG_ERR_NO_DEVICE, PG_ERR_INVALID, PG_ERR_HIP, PG_ERR_UNSUPPORTED, PG_ERR_STATE = -1, -2, -3, -4, -5
 PG_SCORE_ASSERT_FAILED = -1
 PG_K_ANCHOR, PG_K_ALIGN, PG_K_GENOTYPE, PG_K_CALLER_SETUP, PG_K_CALLER_EM = 0, 1, 2, 3, 4
-ABI_VERSION = 7
+ABI_VERSION = 8
 NOALLOC_MAX_PAIRS, NOALLOC_MAX_INDEL_HAPS = 262144, 65536      # PG_NOALLOC_MAX_* of include/platgpu.h
 
 # every symbol include/platgpu.h declares: (restype, argtypes)
@@ -36,6 +36,7 @@ SYMBOLS = {
     "pg_haps_build": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _i64p, _i32p, C.c_int, _i32p, _i32p, _i32p, _i32p, _i32p, C.c_void_p]),
     "pg_haps_fetch": (C.c_int, [C.c_void_p, C.c_void_p, _i64p]),
     "pg_reads_upload": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _i64p, _i32p, _i32p]),
+    "pg_reads_upload_nibbles": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, _i64p, _i32p, _i32p]),
     "pg_pairs_upload": (C.c_int, [C.c_void_p, C.c_int64, _i32p, _i32p]),
     "pg_pairs_block": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "pg_pairs_blocks": (C.c_int, [C.c_void_p, C.c_int, _i32p, _i32p, _i32p, _i32p, _i64p]),
@@ -118,6 +119,23 @@ def pinned_array(shape, dtype):
 _PINNED = {}
 
 
+NIBBLE_CODES = b"=ACMGRSVTWYHKDBN"                     # bam_nt16_rev_table
+
+
+def pack_nibbles(seq):
+    """bases (uint8 characters of NIBBLE_CODES) two per byte, the first in the high half: the form
+    pg_reads_upload_nibbles takes"""
+    seq = np.ascontiguousarray(seq, dtype=np.uint8)
+    code = np.full(256, 255, dtype=np.uint8)
+    code[np.frombuffer(NIBBLE_CODES, dtype=np.uint8)] = np.arange(16, dtype=np.uint8)
+    c = code[seq]
+    if (c == 255).any():
+        raise ValueError("a base outside %r" % NIBBLE_CODES)
+    if len(c) & 1:
+        c = np.concatenate([c, np.zeros(1, dtype=np.uint8)])
+    return (c[0::2] << 4) | c[1::2]
+
+
 def device_count():
     """gfx950 devices this process can open (initialises the HIP runtime)"""
     n = C.c_int(0)
@@ -192,6 +210,13 @@ class AlignContext(object):
         seq = _arr(seq, np.uint8); qual = _arr(qual, np.uint8); off = _arr(off, np.int64)
         pos = _arr(pos, np.int32); mapq = _arr(mapq, np.int32)
         self._check(LIB.pg_reads_upload(self._h, len(off) - 1, _ptr(seq), _ptr(qual), _ptr(off), _ptr(pos), _ptr(mapq)))
+
+    def upload_reads_nibbles(self, seq4, qual, off, pos, mapq):
+        """reads whose bases come two per byte in BAM's 4-bit code (include/platgpu.h: pg_reads_upload_nibbles)"""
+        seq4 = _arr(seq4, np.uint8); qual = _arr(qual, np.uint8); off = _arr(off, np.int64)
+        pos = _arr(pos, np.int32); mapq = _arr(mapq, np.int32)
+        assert len(seq4) >= (int(off[-1]) + 1) // 2
+        self._check(LIB.pg_reads_upload_nibbles(self._h, len(off) - 1, _ptr(seq4), _ptr(qual), _ptr(off), _ptr(pos), _ptr(mapq)))
 
     def upload_batch(self, b):
         """Haplotypes, reads and pairs of a packed batch (see platypus_amd.synth)."""

@@ -25,6 +25,8 @@ cdef extern from "platgpu.h":
     int pg_haps_fetch(pg_ctx* ctx, char* seq, int64_t* offsets)
     int pg_reads_upload(pg_ctx* ctx, int n, const char* seq, const char* qual, const int64_t* offsets,
                         const int32_t* pos, const int32_t* mapq)
+    int pg_reads_upload_nibbles(pg_ctx* ctx, int n, const unsigned char* seq4, const char* qual, const int64_t* offsets,
+                                const int32_t* pos, const int32_t* mapq)
     int pg_pairs_upload(pg_ctx* ctx, int64_t n_pairs, const int32_t* hap_idx, const int32_t* read_idx)
     int pg_pairs_block(pg_ctx* ctx, int hap_lo, int hap_hi, int read_lo, int read_hi)
     int pg_align_launch(pg_ctx* ctx)

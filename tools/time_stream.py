@@ -37,9 +37,10 @@ def link_rate():
     return max(rates[1:])
 
 
-def measure(W=32768, N=12, pinned=True, device=0, batch=None, threads=2, built=False):
+def measure(W=32768, N=12, pinned=True, device=0, batch=None, threads=2, built=False, nibbles=False):
     """built: the haplotypes go up as reference stretches and variant lists and are put together on the device
-    (pg_haps_build) instead of as whole sequences (pg_haps_upload)"""
+    (pg_haps_build) instead of as whole sequences (pg_haps_upload); nibbles: the reads' bases go up two per byte in
+    BAM's 4-bit code (pg_reads_upload_nibbles) instead of as characters"""
     b = batch if batch is not None else synth.make_batch(n_windows=W, haps_per_window=H, reads_per_window=R, read_len=L)
     n_pairs = W * H * R
 
@@ -53,6 +54,7 @@ def measure(W=32768, N=12, pinned=True, device=0, batch=None, threads=2, built=F
     src = {k: host(b[k]) for k in ("hap_seq", "hap_off", "hap_start", "hap_varlen", "read_seq", "read_qual", "read_off",
                                    "read_pos", "read_mapq")}
     bsrc = {k: host(v) for k, v in b["built"].items()} if built else None
+    seq4 = host(native.pack_nibbles(b["read_seq"])) if nibbles else None
     blk = dict(hap_lo=np.arange(W, dtype=np.int32) * H, n_haps=np.full(W, H, np.int32),
                read_lo=np.arange(W, dtype=np.int32) * R, n_reads=np.full(W, R, np.int32))
     n_ctx = max(2, int(threads))
@@ -65,7 +67,10 @@ def measure(W=32768, N=12, pinned=True, device=0, batch=None, threads=2, built=F
             c.build_haps(**bsrc)
         else:
             c.upload_haps(src["hap_seq"], src["hap_off"], src["hap_start"], src["hap_varlen"])
-        c.upload_reads(src["read_seq"], src["read_qual"], src["read_off"], src["read_pos"], src["read_mapq"])
+        if nibbles:
+            c.upload_reads_nibbles(seq4, src["read_qual"], src["read_off"], src["read_pos"], src["read_mapq"])
+        else:
+            c.upload_reads(src["read_seq"], src["read_qual"], src["read_off"], src["read_pos"], src["read_mapq"])
         c.pairs_blocks(blk["hap_lo"], blk["n_haps"], blk["read_lo"], blk["n_reads"])
         c.launch()                               # asynchronous: the kernels run while the other context uploads
 
@@ -119,11 +124,14 @@ def measure(W=32768, N=12, pinned=True, device=0, batch=None, threads=2, built=F
     up = sum(src[k].nbytes for k in src if not (built and k in hap_keys)) + sum(v.nbytes for v in blk.values())
     if built:
         up += sum(v.nbytes for v in bsrc.values())
+    if nibbles:
+        up += seq4.nbytes - src["read_seq"].nbytes
     return dict(ms_per_batch=dt * 1e3, gcups=n_pairs * 16 * (L + 8) / dt / 1e9, pairs_per_s=n_pairs / dt, batches=N,
                 pairs_per_batch=n_pairs, bytes_up=up, bytes_down=n_pairs * 16, upload_gbps=up / dt / 1e9,
                 host_memory="page-locked (pg_host_alloc)" if pinned else "pageable", results_equal_across_batches=same,
                 host_threads=n_ctx if threads else 1, checksum=checksum,
-                haplotypes="reference stretches and variant lists, put together on the device" if built else "whole sequences")
+                haplotypes="reference stretches and variant lists, put together on the device" if built else "whole sequences",
+                read_bases="two per byte (BAM's 4-bit code)" if nibbles else "characters")
 
 
 if __name__ == "__main__":
@@ -131,10 +139,10 @@ if __name__ == "__main__":
     N = int(sys.argv[2]) if len(sys.argv) > 2 else 12
     pinned = (int(sys.argv[3]) if len(sys.argv) > 3 else 1) != 0
     print("host-to-device copy of 256 MiB from page-locked memory: %.1f GB/s" % link_rate())
-    for threads, built in ((0, False), (2, False), (3, False), (4, False), (4, True)):
-      m = measure(W, N, pinned, threads=threads, built=built)
+    for threads, built, nibbles in ((0, False, False), (2, False, False), (4, False, False), (4, True, False), (6, True, False), (4, True, True), (6, True, True), (8, True, True)):
+      m = measure(W, N, pinned, threads=threads, built=built, nibbles=nibbles)
       assert m["results_equal_across_batches"]
-      print("host threads: %d; haplotypes: %s" % (m["host_threads"], m["haplotypes"]))
+      print("host threads: %d; haplotypes: %s; read bases: %s" % (m["host_threads"], m["haplotypes"], m["read_bases"]))
       print("%s host memory, %d batches of %d pairs: %.2f ms per batch = %.0f GCUPS (%.1f M pairs/s); up %.0f MB (%.1f GB/s if "
             "transfers alone filled the time), down %.0f MB" % (m["host_memory"], m["batches"], m["pairs_per_batch"],
                                                                 m["ms_per_batch"], m["gcups"], m["pairs_per_s"] / 1e6,
