@@ -53,6 +53,10 @@ def make(seed):
     n = len(b["pair_hap"])
     b["dense"] = (b["pair_hap"].copy(), b["pair_read"].copy()) if rng.random() < 1.0 / 3 else None
     b["align_kernel"] = str(rng.choice(["default", "default", "lane", "band"]))
+    # how the batch goes up: haplotypes whole or as stretches and variant lists (pg_haps_build), read bases as characters
+    # or two per byte (pg_reads_upload_nibbles)
+    b["build_haps"] = bool(rng.random() < 0.4)
+    b["nibbles"] = bool(rng.random() < 0.4)
     pick = rng.integers(0, n, size=int(rng.integers(1, 2 * n + 1)))
     b["pair_hap"], b["pair_read"] = b["pair_hap"][pick].copy(), b["pair_read"][pick].copy()
     params = (3, 2, po.HOMOPOLQ)
@@ -87,7 +91,15 @@ def main():
                                             b["hap_varlen"][w * H:(w + 1) * H], b["read_seq"], b["read_qual"],
                                             b["read_off"][w * R:(w + 1) * R + 1], b["read_pos"][w * R:(w + 1) * R],
                                             b["read_mapq"][w * R:(w + 1) * R]) for w in range(m["windows"])]
-            ctx.upload_batch(b)
+            if b["build_haps"]:
+                ctx.build_haps(**b["built"])
+            else:
+                ctx.upload_haps(b["hap_seq"], b["hap_off"], b["hap_start"], b["hap_varlen"])
+            if b["nibbles"]:
+                ctx.upload_reads_nibbles(native.pack_nibbles(b["read_seq"]), b["read_qual"], b["read_off"], b["read_pos"], b["read_mapq"])
+            else:
+                ctx.upload_reads(b["read_seq"], b["read_qual"], b["read_off"], b["read_pos"], b["read_mapq"])
+            ctx.upload_pairs(b["pair_hap"], b["pair_read"])
             ctx.launch()
             score, anchor, like = ctx.fetch()
         except native.PlatGpuError as e:
