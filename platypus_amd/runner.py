@@ -58,6 +58,11 @@ def call_chunks(chunks, args, tmpdir):
     stretch is being called."""
     from concurrent.futures import ThreadPoolExecutor
     from platypus_amd import bamio, pipeline, simulate, vcfout
+    import gc
+    # A stretch makes a few hundred thousand small objects (variants, haplotypes, calls) that live until it has been
+    # written, and the interpreter's cycle collector walks the young ones after every 700 allocations by default: a sixth
+    # of the calling thread's time for nothing -- the stretch's objects hold no cycles.  It stays on, at a longer interval.
+    gc.set_threshold(100000, 50, 100)
     from platypus_amd.fastafile import FastaFile
     fa = FastaFile(args.refFile, args.refFile + ".fai", parseNCBI=bool(args.parseNCBI))
     readers = [bamio.BamReader(b) for b in args.bamFiles.split(",")]
