@@ -63,6 +63,10 @@ def call_chunks(chunks, args, tmpdir):
     # written, and the interpreter's cycle collector walks the young ones after every 700 allocations by default: a sixth
     # of the calling thread's time for nothing -- the stretch's objects hold no cycles.  It stays on, at a longer interval.
     gc.set_threshold(100000, 50, 100)
+    # A helper thread needs the interpreter lock for a moment between its long steps outside it; at the default interval a
+    # helper waits up to 5 ms each time while the calling thread computes, and the stretches arrive late (measured: 4 %
+    # of a one-process run).  The calling thread gives way after 50 us instead.
+    sys.setswitchinterval(5e-5)
     from platypus_amd.fastafile import FastaFile
     fa = FastaFile(args.refFile, args.refFile + ".fai", parseNCBI=bool(args.parseNCBI))
     readers = [bamio.BamReader(b) for b in args.bamFiles.split(",")]
