@@ -35,3 +35,14 @@ def test_no_device_is_an_error_not_a_fallback():
         assert e.code == native.PG_ERR_NO_DEVICE
     else:
         raise AssertionError("context creation must fail without a device")
+
+
+def test_nibble_packing_is_the_bam_code():
+    """pack_nibbles writes what a BAM record holds (bam1_seq: two bases per byte, the first in the high half, codes of
+    bam_nt16_rev_table "=ACMGRSVTWYHKDBN", platypus/c/samtools/bam.h)"""
+    import numpy as np
+    from platypus_amd import native
+    assert native.NIBBLE_CODES == b"=ACMGRSVTWYHKDBN"
+    seq = np.frombuffer(b"ACGTN=M", dtype=np.uint8)
+    assert native.pack_nibbles(seq).tolist() == [0x12, 0x48, 0xF0, 0x30]
+    assert native.pack_nibbles(seq[:0]).tolist() == []
